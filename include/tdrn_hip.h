@@ -1,0 +1,220 @@
+/*
+ * tdrn_hip.h -- C ABI of libtdrn_hip.so: the MI355X (gfx950) inference path of TDRN's
+ * dual-refinement detector.  Plain pointers and sizes only (no torch / THC types).
+ *
+ * Conventions:
+ *   - return 0 (TDRN_OK) on success; NEGATIVE = argument / shape error (the reference's
+ *     shape_check / THArgCheck cases); POSITIVE = hipError_t of a failed HIP call.  Nothing
+ *     is printf'ed-and-ignored (the reference does: deform_conv_cuda_kernel.cu:233-237,
+ *     nms_kernel.cu:12-19).
+ *   - every device buffer is owned by the caller (PyTorch-ROCm allocates them); functions that
+ *     need scratch take a (workspace, workspace_bytes) pair sized by the matching
+ *     *_workspace_bytes() query.  No hipMalloc / hipFree / device sync inside the hot calls
+ *     (so they can be captured into a hipGraph); the two exceptions are marked COMPAT.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     enqueued on it and the call returns without synchronising unless stated.
+ *   - thread-safe per (handle, stream); no global mutable state.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the upstream
+ * SeanChenxy/TDRN tree).
+ */
+#ifndef TDRN_HIP_H
+#define TDRN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDRN_API __attribute__((visibility("default")))
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define TDRN_OK 0
+#define TDRN_E_ARG (-1)          /* null pointer / bad enum / bad size                          */
+#define TDRN_E_SHAPE (-2)        /* shape_check failure (deform_conv_cuda.c:7-96)               */
+#define TDRN_E_WORKSPACE (-3)    /* workspace too small                                         */
+#define TDRN_E_UNSUPPORTED (-4)  /* configuration outside what the kernels cover                */
+#define TDRN_E_PARAM (-5)        /* unknown / missing / mis-shaped state_dict entry             */
+#define TDRN_E_STATE (-6)        /* call order (e.g. forward before weights were packed)        */
+#define TDRN_E_VALUE (-7)        /* Detect: nms_thresh <= 0 (layers/functions/detection.py:20)  */
+
+TDRN_API const char *tdrn_version(void);
+TDRN_API const char *tdrn_error_string(int code);
+
+/* arithmetic type of the dense path (activations + weights in HBM, MFMA input type);
+ * accumulation is always fp32; box decoding / NMS / offsets / bilinear weights always fp32. */
+typedef enum { TDRN_F32 = 0, TDRN_BF16 = 1, TDRN_F16 = 2 } tdrn_dtype;
+
+/* ========================================================================================
+ * (i) Deformable convolution v1 forward -- replaces
+ *     int deform_conv_forward_cuda(THCudaTensor *input, *weight, *offset, *output, *columns,
+ *         *ones, int kW, int kH, int dW, int dH, int padW, int padH, int dilationH,
+ *         int dilationW, int deformable_group)          utils/deformconv/deform_conv_cuda.h:1-7
+ *     called from ConvOffset2dFunction.forward          model/networks.py:641-645
+ *     kernel semantics                                  utils/deformconv/deform_conv_cuda_kernel.cu:15-51,156-208
+ *   input  (N, Cin, H, W)  fp32 NCHW contiguous, device
+ *   weight (Cout, Cin, kH, kW) fp32 contiguous, device        (no bias, like the reference)
+ *   offset (N, G*2*kH*kW, Ho, Wo) fp32, device
+ *   output (N, Cout, Ho, Wo) fp32, device, fully overwritten
+ *   `columns` / `ones` of the reference have no counterpart: the sampled columns never leave
+ *   LDS.  `compute` selects the MFMA input type (TDRN_F32 reproduces the reference's fp32).
+ *   Shape errors mirror shape_check (deform_conv_cuda.c:7-96, :137) -> TDRN_E_SHAPE.
+ * ====================================================================================== */
+TDRN_API size_t tdrn_deform_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kH,
+                                                 int kW, int dH, int dW, int padH, int padW,
+                                                 int dilationH, int dilationW,
+                                                 int deformable_group, tdrn_dtype compute);
+TDRN_API int tdrn_deform_conv_forward(const float *input, const float *weight,
+                                      const float *offset, float *output, int N, int Cin, int H,
+                                      int W, int Cout, int kW, int kH, int dW, int dH, int padW,
+                                      int padH, int dilationH, int dilationW,
+                                      int deformable_group, tdrn_dtype compute, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+
+/* ========================================================================================
+ * (ii) NMS / box utilities / Detect
+ * ====================================================================================== */
+
+/* Greedy NMS with the CPU semantics Detect uses -- replaces
+ *     cpu_nms(ndarray[float32, ndim=2] dets, float thresh) -> list   utils/nms/cpu_nms.pyx:17-68
+ *     (dispatcher utils/nms_wrapper.py:23-31, called at layers/functions/detection.py:60)
+ *   dets (n,5) device fp32 rows [x1,y1,x2,y2,score] in pixel units ("+1" convention), ANY order;
+ *   sorted on device by (score desc, index asc).  Suppression when IoU >= thresh
+ *   (strict_gt = 0, cpu_nms.pyx:66) or IoU > thresh (strict_gt = 1, nms_kernel.cu:71); the IoU
+ *   is fp32 and compared against the double `thresh` exactly as the Cython code does.
+ *   keep_out (n) device int32 <- kept indices into dets, descending score; num_out (1) device. */
+TDRN_API size_t tdrn_nms_workspace_bytes(int n);
+TDRN_API int tdrn_nms(const float *dets, int n, double thresh, int strict_gt, int32_t *keep_out,
+                      int32_t *num_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* COMPAT twin of   void _nms(int* keep_out, int* num_out, const float* boxes_host,
+ *     int boxes_num, int boxes_dim, float nms_overlap_thresh, int device_id)
+ *                                                          utils/nms/gpu_nms.hpp:1-2
+ *   HOST pointers in and out, boxes already sorted descending by the caller
+ *   (gpu_nms.pyx:25-28), strict `>` threshold (nms_kernel.cu:71), synchronous, allocates and
+ *   frees device memory per call like the reference (nms_kernel.cu:100-143).  Not hot path. */
+TDRN_API int tdrn_gpu_nms_host(int *keep_out, int *num_out, const float *boxes_host,
+                               int boxes_num, int boxes_dim, float nms_overlap_thresh,
+                               int device_id);
+
+/* decode / center_size -- layers/box_utils.py:176-195, :16-25.  Device fp32 (P,4) arrays. */
+TDRN_API int tdrn_decode(const float *loc, const float *priors, int P, float var0, float var1,
+                         float *boxes_out, void *stream);
+TDRN_API int tdrn_center_size(const float *boxes, int P, float *out, void *stream);
+
+/* PriorBox.forward -- layers/functions/prior_box.py:33-64 (host, double arithmetic, cast to
+ * fp32, clamp).  aspect_ratios ragged: ar_count[k] values per map, concatenated in `ars`.
+ * out == NULL: returns the number of priors only.  Returns P (>= 0) or a negative error. */
+TDRN_API int tdrn_prior_box(int n_maps, const int *feature_maps, double image_size,
+                            const double *steps, const double *min_sizes,
+                            const double *max_sizes, int n_max_sizes, const int *ar_count,
+                            const double *ars, int clip, int flip, float *out_host);
+
+/* Detect.forward -- layers/functions/detection.py:25-70, fully on device, batched over
+ * (image, class):  two-stage decode (:43-48), score > conf_thresh (:53), boxes*scale (:59),
+ * cpu_nms semantics (:60), first top_k survivors packed as [score,x1,y1,x2,y2] (:61-63).
+ *   loc (B,P,4)  conf (B*P,C)  priors (P,4)  arm_loc (B,P,4) or NULL  -- device fp32
+ *   scale: 4 HOST floats (the caller's [w,h,w,h]; evaluate.py:461)
+ *   out (B,C,top_k,5) device fp32, fully overwritten (class 0 and unused slots = 0)
+ *   counts_out (B*C) device int32 or NULL: survivors per (image,class), capped at top_k. */
+TDRN_API size_t tdrn_detect_workspace_bytes(int B, int P, int C, int top_k);
+TDRN_API int tdrn_detect(const float *loc, const float *conf, const float *priors,
+                         const float *arm_loc, const float *scale_host, int B, int P, int C,
+                         int top_k, float conf_thresh, double nms_thresh, float *out,
+                         int32_t *counts_out, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* ========================================================================================
+ * (iii) Whole-network forward -- replaces build_net(...)/RefineSSD.forward:
+ *     model/dualrefinedet_vggbn.py:10-117,119-206,217-222   (TDRN_DRN_VGGBN)
+ *     model/dualrefinedet_mobilenet.py:8-125,127-199        (TDRN_DRN_MOBILENET)
+ *     model/ssd4scale_mobile.py:9-84,86-140                 (TDRN_SSD4SCALE_MOBILE)
+ *     model/refinedet_vgg.py:112-219                        (TDRN_REFINEDET_VGG)
+ *     model/ssd4scale_vgg.py:71-135                         (TDRN_SSD4SCALE_VGG)
+ * ====================================================================================== */
+typedef enum {
+    TDRN_DRN_VGGBN = 0,
+    TDRN_DRN_MOBILENET = 1,
+    TDRN_SSD4SCALE_MOBILE = 2,
+    TDRN_REFINEDET_VGG = 3,
+    TDRN_SSD4SCALE_VGG = 4
+} tdrn_model;
+
+typedef struct {
+    int model;        /* tdrn_model                                                         */
+    int size;         /* 320 or 512 (build_net rejects anything else)                       */
+    int num_classes;  /* 21                                                                 */
+    int c7_channel;   /* 1024                                                               */
+    int def_groups;   /* deformable groups of the ODM heads (1)                             */
+    int bn;           /* VGG trunk with BatchNorm                                           */
+    int multihead;    /* 5x5 deformable heads summed with the 3x3 ones                      */
+    int deform;       /* ssd4scale_*: deformable ARM heads (df_group = 8), TRN temporal net */
+    int test_phase;   /* 1: softmax on conf (phase == 'test'); 0: raw logits                */
+    int dtype;        /* tdrn_dtype of the dense path                                       */
+    int reserved[6];
+} tdrn_net_config;
+
+typedef struct tdrn_net tdrn_net;
+
+/* Builds the layer plan on the host (no device work). */
+TDRN_API int tdrn_net_create(const tdrn_net_config *cfg, tdrn_net **out);
+TDRN_API void tdrn_net_destroy(tdrn_net *net);
+
+/* state_dict interface: names and shapes are the reference's (entries ending in
+ * num_batches_tracked are not parameters and are rejected with TDRN_E_PARAM).
+ * tdrn_net_param_count/info enumerate what the plan expects, in the reference's order. */
+TDRN_API int tdrn_net_param_count(const tdrn_net *net);
+TDRN_API int tdrn_net_param_info(const tdrn_net *net, int index, const char **name,
+                                 int64_t shape[4], int *ndim);
+/* Copies one fp32 HOST tensor into the net's staging area. */
+TDRN_API int tdrn_net_set_param(tdrn_net *net, const char *name, const float *data_host,
+                                int64_t numel);
+
+/* Device memory the caller must provide. */
+TDRN_API size_t tdrn_net_weight_bytes(const tdrn_net *net);
+TDRN_API size_t tdrn_net_workspace_bytes(const tdrn_net *net, int batch);
+TDRN_API int tdrn_net_num_priors(const tdrn_net *net);
+
+/* Folds BatchNorm into the preceding conv, repacks OIHW -> [Cout_pad][kh][kw][Cin] in the
+ * net's dtype, and uploads the blob (synchronous; one-time).  Every expected parameter must
+ * have been set.  Ranks that receive the blob by RCCL broadcast skip this call and use
+ * tdrn_net_adopt_weights() instead. */
+TDRN_API int tdrn_net_pack_weights(tdrn_net *net, void *weights_dev, size_t weights_bytes,
+                                   void *stream);
+TDRN_API int tdrn_net_adopt_weights(tdrn_net *net);
+
+typedef struct {
+    const float *x;        /* (B,3,S,S) fp32 NCHW, mean-subtracted 0..255 range, device      */
+    int batch;
+    float *arm_loc;        /* (B,P,4) fp32; DRN/RefineDet: ARM loc; ssd4scale: the loc output */
+    float *odm_loc;        /* (B,P,4) fp32; NULL for ssd4scale                               */
+    float *conf;           /* (B*P,C) fp32 softmax (test phase) or logits                    */
+    float *offsets[4];     /* optional (B,G*18,H,W) fp32 NCHW out (arm_offset_list); or NULL */
+    const float *ref_loc[4]; /* ssd4scale deform=1: (B,12,H,W) fp32 NCHW loc maps IN        */
+    float *loc_maps[4];    /* ssd4scale ret_loc: (B,12,H,W) fp32 NCHW raw loc maps OUT       */
+    void *reserved[4];
+} tdrn_net_io;
+
+TDRN_API int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *workspace,
+                              size_t workspace_bytes, const tdrn_net_io *io, void *stream);
+
+/* Per-kernel accounting of the LAST forward for bench.py's roofline line: algorithmic FLOPs
+ * and bytes per kernel family, and (when profiling is enabled) hipEvent-measured time.
+ * tdrn_net_profile(net, 1) makes the next forwards record an event pair around every launch
+ * on `stream` (adds launch gaps: use only in a dedicated profiling pass). */
+typedef struct {
+    char name[48];
+    int launches;
+    double flops;        /* algorithmic FLOPs (2*MAC) of all launches                        */
+    double bytes;        /* algorithmic HBM bytes (inputs + weights + outputs, once each)   */
+    double ms;           /* summed launch durations (profiling on), else 0                   */
+} tdrn_kernel_stat;
+TDRN_API int tdrn_net_profile(tdrn_net *net, int enable);
+TDRN_API int tdrn_net_kernel_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDRN_HIP_H */

@@ -1,0 +1,283 @@
+// deform.hip -- deformable convolution v1 forward as ONE fused kernel: bilinear gather of NHWC
+// feature rows straight into the LDS operand tile, then MFMA.  Replaces the reference's
+// per-image deformable_im2col kernel + cuBLAS SGEMM with its column buffer round trip through
+// global memory (utils/deformconv/deform_conv_cuda_kernel.cu:156-238, deform_conv_cuda.c:157-193).
+//
+// Sampling semantics follow deform_conv_cuda_kernel.cu:15-51 and :189-203 exactly, including the
+// asymmetric border rule: any negative coordinate or coordinate >= H (W) gives 0; coordinates in
+// (H-1, H) clamp to row H-1 with fraction 0 (no zero-padding decay on the bottom/right edge).
+// Offsets and bilinear weights are fp32 in every mode.
+//
+// Up to two branches (the 3x3 and the 5x5 "multihead" heads, model/dualrefinedet_vggbn.py:181-187)
+// and several heads stacked along Cout (loc = 12, conf = 63 channels) share one launch: the sum
+// l(ob,f) + l2(ob,f2) is just a longer K loop, and loc/conf are column segments of the same GEMM.
+#include "kernels.h"
+
+namespace tdrn {
+
+struct DeformBranchP {
+    const float *off;
+    const char *w;
+    int off_stride, kh, kw, pad, stride, dil, G, pad_;
+};
+struct DeformParams {
+    const char *in, *zero;
+    DeformBranchP br[2];
+    int n_branches;
+    int M, H, W, Cin, Ho, Wo, Cout, Npad, split;
+    float *out0, *out1;
+    long long o0_bs, o0_ps, o1_bs, o1_ps;
+};
+
+template <typename DT> struct MmaD;
+template <> struct MmaD<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4 &a, const u32x4 &b, f32x16 &c)
+    { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(i16x8, a), __builtin_bit_cast(i16x8, b), c, 0, 0, 0); }
+};
+template <> struct MmaD<f16_t> {
+    __device__ static __forceinline__ void run(const u32x4 &a, const u32x4 &b, f32x16 &c)
+    { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
+};
+template <> struct MmaD<float> {
+    __device__ static __forceinline__ void run(const u32x4 &a, const u32x4 &b, f32x16 &c)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    }
+};
+
+// 128 pixels x (NTL*32) couts per workgroup; wave w owns pixels [32w, 32w+32) and all cout tiles.
+template <typename DT, int NTL>
+__global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
+{
+    constexpr int BM = 128, BN = NTL * 32, NT = 256, RPP = 32, PA = BM / RPP;
+    constexpr int ES = elem_traits<DT>::bytes;
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int CK = 128 / ES;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int CS = BN * 4 + 16;
+    constexpr int LDS = (2 * STAGE > BM * CS) ? 2 * STAGE : BM * CS;
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lrow = t >> 3, pc = t & 7;
+    const int lc16 = (pc ^ ((lrow >> 1) & 7)) << 4;
+    const int m0 = blockIdx.x * BM;
+    const int HoWo = p.Ho * p.Wo;
+
+    int ho_[PA], wo_[PA], ibase[PA];
+    long long mrow[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + i * RPP + lrow;
+        if (m < p.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            ho_[i] = rem / p.Wo;
+            wo_[i] = rem - ho_[i] * p.Wo;
+            ibase[i] = b * p.H * p.W * p.Cin;
+            mrow[i] = m;
+        } else {
+            ho_[i] = 0; wo_[i] = 0; ibase[i] = 0; mrow[i] = -1;
+        }
+    }
+
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int ci = 0; ci < NTL; ++ci)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ci][e] = 0.f;
+
+    // K-loop cursor: branch, tap (ti,tj), group g, channel chunk cc inside the group
+    int br = 0, ti = 0, tj = 0, g = 0, cc = 0, kofs = 0;
+    int coff[PA][4];      // element offsets of the four corners (relative to `in`)
+    float cw[PA][4];      // bilinear weights (0 when the tap is rejected)
+
+    auto tap_params = [&]() {
+        const DeformBranchP &B = p.br[br];
+        const int tapidx = ti * B.kw + tj;
+        const int cpg = p.Cin / B.G;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+            int o1 = ibase[i], o2 = ibase[i], o3 = ibase[i], o4 = ibase[i];
+            if (mrow[i] >= 0) {
+                const float *op = B.off + mrow[i] * B.off_stride + (size_t)g * 2 * B.kh * B.kw + 2 * tapidx;
+                const float offset_h = op[0], offset_w = op[1];
+                const int h_in = ho_[i] * B.stride - B.pad, w_in = wo_[i] * B.stride - B.pad;
+                const float h_im = (float)(h_in + ti * B.dil) + offset_h;
+                const float w_im = (float)(w_in + tj * B.dil) + offset_w;
+                if (h_im >= 0.f && w_im >= 0.f && h_im < (float)p.H && w_im < (float)p.W) {
+                    float h = (float)(ti * B.dil) + offset_h;     // map_h, relative to h_in
+                    float w = (float)(tj * B.dil) + offset_w;
+                    const int height = p.H - h_in, width = p.W - w_in;
+                    int h_low = (int)floorf(h), w_low = (int)floorf(w), h_high, w_high;
+                    if (h_low >= height - 1) { h_high = h_low = height - 1; h = (float)h_low; } else { h_high = h_low + 1; }
+                    if (w_low >= width - 1) { w_high = w_low = width - 1; w = (float)w_low; } else { w_high = w_low + 1; }
+                    const float lh = h - (float)h_low, lw = w - (float)w_low;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    w1 = hh * hw; w2 = hh * lw; w3 = lh * hw; w4 = lh * lw;
+                    // absolute coordinates (clamped only for memory safety; a no-op whenever the
+                    // reference itself stays in bounds)
+                    const int r0 = min(max(h_in + h_low, 0), p.H - 1), r1 = min(max(h_in + h_high, 0), p.H - 1);
+                    const int q0 = min(max(w_in + w_low, 0), p.W - 1), q1 = min(max(w_in + w_high, 0), p.W - 1);
+                    const int gb = ibase[i] + g * cpg;
+                    o1 = gb + (r0 * p.W + q0) * p.Cin;
+                    o2 = gb + (r0 * p.W + q1) * p.Cin;
+                    o3 = gb + (r1 * p.W + q0) * p.Cin;
+                    o4 = gb + (r1 * p.W + q1) * p.Cin;
+                }
+            }
+            coff[i][0] = o1; coff[i][1] = o2; coff[i][2] = o3; coff[i][3] = o4;
+            cw[i][0] = w1; cw[i][1] = w2; cw[i][2] = w3; cw[i][3] = w4;
+        }
+    };
+
+    auto produce = [&](int buf) {
+        char *sb = smem + buf * STAGE;
+        const DeformBranchP &B = p.br[br];
+        // weights: LDS-DMA, swizzle on the source address
+        const int Ktot = B.kh * B.kw * p.Cin;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+            const char *src = B.w + ((size_t)(i * RPP + lrow) * Ktot + kofs) * ES + lc16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sb + (i * RPP + wave * 8) * 128), 16, 0, 0);
+        }
+        // sampled activations: 4 corner rows -> fp32 blend -> DT -> LDS (physical chunk pc)
+        const int coffs = cc * CK * ES + lc16;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            u32x4 raw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4 *)(p.in + (size_t)coff[i][k] * ES + coffs);
+            float v[4][P16], o[P16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) unpack16<DT>(raw[k], v[k]);
+#pragma unroll
+            for (int j = 0; j < P16; ++j)
+                o[j] = fmaf(cw[i][3], v[3][j], fmaf(cw[i][2], v[2][j], fmaf(cw[i][1], v[1][j], cw[i][0] * v[0][j])));
+            *(u32x4 *)(sb + BN * 128 + (i * RPP + lrow) * 128 + pc * 16) = pack16<DT>(o);
+        }
+    };
+
+    // returns false when the K loop is exhausted; recomputes tap params when (tap, group) changes
+    auto advance = [&]() -> bool {
+        const DeformBranchP &B = p.br[br];
+        const int cpg = p.Cin / B.G;
+        kofs += CK;
+        if (++cc < cpg / CK) return true;
+        cc = 0;
+        if (++g == B.G) {
+            g = 0;
+            if (++tj == B.kw) { tj = 0; ++ti; }
+            if (ti == B.kh) {
+                ti = 0; kofs = 0;
+                if (++br == p.n_branches) return false;
+            }
+        }
+        tap_params();
+        return true;
+    };
+
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int sw = (r32 >> 1) & 7;
+    auto compute = [&](int buf) {
+        const char *wsb = smem + buf * STAGE;
+        const char *psb = wsb + BN * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = ((2 * kk + hh) ^ sw) << 4;
+            const u32x4 pf = *(const u32x4 *)(psb + (wave * 32 + r32) * 128 + ch);
+#pragma unroll
+            for (int ci = 0; ci < NTL; ++ci) {
+                const u32x4 wf = *(const u32x4 *)(wsb + (ci * 32 + r32) * 128 + ch);
+                MmaD<DT>::run(wf, pf, acc[ci]);
+            }
+        }
+    };
+
+    tap_params();
+    produce(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    bool more = true;
+    while (more) {
+        more = advance();
+        if (more) produce(cur ^ 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: transpose through LDS, then split the channel range into the two outputs ----
+#pragma unroll
+    for (int ci = 0; ci < NTL; ++ci)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[ci][4 * q + j];
+            *(f32x4 *)(smem + (wave * 32 + r32) * CS + (ci * 32 + 8 * q + 4 * hh) * 4) = v;
+        }
+    __syncthreads();
+    for (int idx = t; idx < BM * p.Cout; idx += NT) {
+        const int row = idx / p.Cout, c = idx - row * p.Cout;
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        const int b = m / HoWo, pix = m - b * HoWo;
+        const float v = *(const float *)(smem + row * CS + c * 4);
+        if (c < p.split) p.out0[b * p.o0_bs + pix * p.o0_ps + c] = v;
+        else p.out1[b * p.o1_bs + pix * p.o1_ps + (c - p.split)] = v;
+    }
+}
+
+int deform_n_pad(int cout) { return (int)align_up((size_t)cout, 32); }
+
+template <typename DT> static int launch_deform_dt(const DeformParams &p, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv(p.M, 128));
+    switch (p.Npad / 32) {
+        case 1: hipLaunchKernelGGL((deform_gemm_kernel<DT, 1>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((deform_gemm_kernel<DT, 2>), grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((deform_gemm_kernel<DT, 3>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((deform_gemm_kernel<DT, 4>), grid, dim3(256), 0, s, p); break;
+        default: return TDRN_E_UNSUPPORTED;
+    }
+    return hip_status(hipGetLastError());
+}
+
+int launch_deform(const DeformArgs &a, hipStream_t s)
+{
+    if (!a.in || !a.out0 || a.n_branches < 1 || a.n_branches > 2) return TDRN_E_ARG;
+    const int es = dtype_bytes(a.dtype), ck = 128 / es;
+    if (a.Npad % 32 || a.Npad > 128 || a.Cout > a.Npad || a.Cout < 1) return TDRN_E_UNSUPPORTED;
+    if (a.split < a.Cout && !a.out1) return TDRN_E_ARG;
+    if ((long long)a.B * a.H * a.W * a.Cin >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
+    DeformParams p;
+    p.in = (const char *)a.in;
+    p.zero = (const char *)a.zero_page;
+    p.n_branches = a.n_branches;
+    for (int i = 0; i < a.n_branches; ++i) {
+        const DeformBranch &b = a.br[i];
+        if (!b.off || !b.w || b.G < 1 || a.Cin % b.G || (a.Cin / b.G) % ck) return TDRN_E_UNSUPPORTED;
+        p.br[i] = DeformBranchP{b.off, (const char *)b.w, b.off_stride, b.kh, b.kw, b.pad, b.stride, b.dil, b.G, 0};
+    }
+    if (a.n_branches == 1) p.br[1] = p.br[0];
+    p.M = a.B * a.Ho * a.Wo;
+    p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.Cout = a.Cout; p.Npad = a.Npad;
+    p.split = a.split > a.Cout ? a.Cout : a.split;
+    p.out0 = a.out0; p.out1 = a.out1;
+    p.o0_bs = a.o0_bs; p.o0_ps = a.o0_ps; p.o1_bs = a.o1_bs; p.o1_ps = a.o1_ps;
+    if (p.M <= 0) return TDRN_OK;
+    switch (a.dtype) {
+        case TDRN_F32: return launch_deform_dt<float>(p, s);
+        case TDRN_BF16: return launch_deform_dt<bf16_t>(p, s);
+        case TDRN_F16: return launch_deform_dt<f16_t>(p, s);
+    }
+    return TDRN_E_ARG;
+}
+
+}  // namespace tdrn

@@ -1,0 +1,115 @@
+// kernels.h -- launch interfaces of the HIP kernels (internal to libtdrn_hip).
+#pragma once
+#include "common.h"
+
+namespace tdrn {
+
+// A device buffer every padding tap / out-of-range row reads instead of branching (16-B aligned,
+// >= 256 zero bytes).  It lives at the start of the caller-provided workspace / weight blob.
+constexpr size_t kZeroPageBytes = 256;
+
+// ---------------------------------------------------------------------------------------------
+// Dense convolution as implicit GEMM on MFMA (conv_igemm.hip).
+//   in  : NHWC [B][H][W][Cin]      (DT; Cin a multiple of the 128-byte K-step)
+//   w   : [phases][Npad][kh*kw][Cin] (DT; BatchNorm folded; rows >= Cout are zero)
+//   out : element (b,ho,wo,c) at  o_base + b*o_bs + ho*o_rs + wo*o_cs + c   (DT or fp32)
+//   res : optional residual with the SAME view as out (DT), added before the ReLU
+//   phases = 4 turns the launch into ConvTranspose2d(k=2,s=2): phase z=(i,j) uses weight slab z
+//   and adds i*o_pr + j*o_pc to o_base.
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const void *in = nullptr, *w = nullptr, *res = nullptr, *zero_page = nullptr;
+    const float *bias = nullptr;   // [phases? no: shared][Npad] fp32
+    void *out = nullptr;
+    int B = 0, H = 0, W = 0, Cin = 0;
+    int Ho = 0, Wo = 0, Cout = 0, Npad = 0;
+    int kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;
+    int relu = 0, out_f32 = 0, phases = 1;
+    long long o_bs = 0, o_rs = 0, o_cs = 0, o_base = 0, o_pr = 0, o_pc = 0;
+    int dtype = TDRN_BF16;
+};
+int launch_conv(const ConvArgs &a, hipStream_t s);
+// rows of the packed weight matrix must be padded to a multiple of this
+int conv_n_pad(int cout);
+// channels of every NHWC activation tensor are padded to a multiple of this
+constexpr int kChanPad = 64;
+
+// ---------------------------------------------------------------------------------------------
+// HBM-bound layer kernels (layers.hip)
+// ---------------------------------------------------------------------------------------------
+// first conv: x NCHW fp32 [B][3][S][S] -> NHWC DT [B][Ho][Wo][Cpad], 3x3, pad 1, stride 1|2,
+// folded BN + ReLU.  w: fp32 [Cout][27] (k = c*9 + r*3 + q), bias fp32 [Cout].
+int launch_first_conv(const float *x, const float *w, const float *bias, void *out, int B, int S,
+                      int stride, int Cout, int Cpad, int relu, int dtype, hipStream_t s);
+// 2x2 stride-2 max pool, NHWC DT, optional ceil_mode
+int launch_maxpool2(const void *in, void *out, int B, int H, int W, int C, int ceil_mode, int dtype,
+                    hipStream_t s);
+// L2Norm over channels: y = w[c] * (x / (sqrt(sum x^2) + 1e-10)), NHWC DT
+int launch_l2norm(const void *in, const float *w, void *out, long long pixels, int C, int dtype,
+                  hipStream_t s);
+// depthwise 3x3, pad 1, stride 1|2, folded BN + ReLU, NHWC DT.  w: fp32 [9][Cpad], bias [Cpad]
+int launch_dwconv3(const void *in, const float *w, const float *bias, void *out, int B, int H, int W,
+                   int C, int stride, int relu, int dtype, hipStream_t s);
+// softmax over rows of (R, C) fp32, in place allowed
+int launch_softmax_rows(const float *in, float *out, long long R, int C, hipStream_t s);
+// 1x1 "offset" convs on the 12-channel ARM loc map: loc fp32 (pixel stride loc_ps, batch stride
+// loc_bs, 12 ch) -> off NHWC fp32 [B*H*W][n_out], w fp32 [n_out][12], bias [n_out] (or null)
+int launch_offset_conv(const float *loc, long long loc_bs, long long loc_ps, const float *w,
+                       const float *bias, float *off, int B, int HW, int n_in, int n_out,
+                       hipStream_t s);
+// layout conversions for the API surfaces that are NCHW fp32
+int launch_nchw_to_nhwc(const float *in, void *out, int B, int C, int HW, int Cpad, int dtype,
+                        hipStream_t s);   // fp32 NCHW -> DT NHWC (channel-padded with zeros)
+int launch_nchw_to_nhwc_grouped(const float *in, void *out, int B, int C, int HW, int G, int cpg_pad, int dtype,
+                                hipStream_t s);
+int launch_repack_oihw(const float *w, void *out, int Cout, int Npad, int Cin, int taps, int G, int cpg_pad, int dtype,
+                       hipStream_t s);
+int launch_nhwc_to_nchw_f32(const float *in, long long in_bs, long long in_ps, float *out, int B,
+                            int C, int HW, hipStream_t s);   // fp32 "NHWC view" -> fp32 NCHW
+int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Deformable-conv GEMM (deform.hip): up to two branches (3x3 + 5x5) sharing the input and summed.
+//   in  : NHWC DT [B][H][W][Cin]
+//   off : NHWC fp32 [B][Ho][Wo][off_stride], branch offsets at off + off_ch0 (G*2*k*k channels,
+//         channel order of the reference: g, then 2*(i*kw+j)+{0:dh,1:dw})
+//   w   : DT [Npad][taps][Cin]
+//   out : fp32, element (pixel m, channel c) at out + m*o_ps + c (c < Cout)
+// ---------------------------------------------------------------------------------------------
+struct DeformBranch {
+    const float *off = nullptr;
+    int off_stride = 0;
+    const void *w = nullptr;
+    int kh = 3, kw = 3, pad = 1, stride = 1, dil = 1, G = 1;
+};
+struct DeformArgs {
+    const void *in = nullptr, *zero_page = nullptr;
+    DeformBranch br[2];
+    int n_branches = 1;
+    int B = 0, H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, Cout = 0, Npad = 0;
+    // two output segments so that loc and conf heads fused into one GEMM land in their own buffers:
+    // channels [0,split) -> out0 (+ b*o0_bs + pix*o0_ps), [split,Cout) -> out1
+    float *out0 = nullptr, *out1 = nullptr;
+    int split = 0;
+    long long o0_bs = 0, o0_ps = 0, o1_bs = 0, o1_ps = 0;
+    int dtype = TDRN_BF16;
+};
+int launch_deform(const DeformArgs &a, hipStream_t s);
+int deform_n_pad(int cout);
+
+// ---------------------------------------------------------------------------------------------
+// Detect (detect.hip)
+// ---------------------------------------------------------------------------------------------
+int launch_decode(const float *loc, const float *priors, int P, float v0, float v1, float *out,
+                  hipStream_t s);
+int launch_center_size(const float *boxes, int P, float *out, hipStream_t s);
+size_t detect_workspace_bytes(int B, int P, int C, int top_k);
+int launch_detect(const float *loc, const float *conf, const float *priors, const float *arm_loc,
+                  const float *scale4, int B, int P, int C, int top_k, float conf_thresh,
+                  double nms_thresh, float *out, int32_t *counts, void *ws, size_t ws_bytes,
+                  hipStream_t s);
+size_t nms_workspace_bytes(int n);
+int launch_nms(const float *dets, int n, double thresh, int strict_gt, int presorted,
+               int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace tdrn

@@ -1,0 +1,397 @@
+// layers.hip -- the HBM-bound layers of the trunk and heads, NHWC, 16 bytes per lane.
+//   first conv (Cin = 3)      model/networks.py:145 (vgg), dualrefinedet_mobilenet.py:20
+//   MaxPool2d 2x2 s2          model/networks.py:141-143,151
+//   L2Norm                    layers/modules/l2norm.py:17-21
+//   depthwise 3x3 + BN + ReLU model/networks.py:736-745
+//   Softmax(dim=1)            model/dualrefinedet_vggbn.py:116-117,196
+//   offset 1x1 convs          model/dualrefinedet_vggbn.py:53-57,71-76,155-164
+#include "kernels.h"
+
+namespace tdrn {
+
+// ---------------------------------------------------------------------------------------------
+// First conv: NCHW fp32 image -> NHWC DT.  One thread = one output pixel; its 27 inputs sit in
+// registers, the folded weights are wave-uniform (scalar loads), outputs leave as 16-B chunks.
+// ---------------------------------------------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, char *__restrict__ out,
+                                                         int B, int S, int So, int stride, int Cout, int Cpad, int relu)
+{
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int ES = elem_traits<DT>::bytes;
+    const long long total = (long long)B * So * So;
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total) return;
+    const int b = (int)(pix / (So * So));
+    const int rem = (int)(pix - (long long)b * So * So);
+    const int ho = rem / So, wo = rem - ho * So;
+    float v[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int hi = ho * stride - 1 + r, wi = wo * stride - 1 + q;
+                const bool ok = (unsigned)hi < (unsigned)S && (unsigned)wi < (unsigned)S;
+                v[c * 9 + r * 3 + q] = ok ? x[(((size_t)b * 3 + c) * S + hi) * S + wi] : 0.f;
+            }
+    char *dst = out + (size_t)pix * Cpad * ES;
+    for (int c0 = 0; c0 < Cpad; c0 += P16) {
+        float o[P16];
+#pragma unroll
+        for (int j = 0; j < P16; ++j) {
+            const int co = c0 + j;          // wave-uniform
+            float acc = 0.f;
+            if (co < Cout) {
+                acc = bias[co];
+#pragma unroll
+                for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+                if (relu) acc = fmaxf(acc, 0.f);
+            }
+            o[j] = acc;
+        }
+        *(u32x4 *)(dst + (size_t)c0 * ES) = pack16<DT>(o);
+    }
+}
+
+int launch_first_conv(const float *x, const float *w, const float *bias, void *out, int B, int S, int stride,
+                      int Cout, int Cpad, int relu, int dtype, hipStream_t s)
+{
+    const int So = (S + 2 - 3) / stride + 1;
+    const long long total = (long long)B * So * So;
+    dim3 grid((unsigned)((total + 255) / 256));
+#define L(DT) hipLaunchKernelGGL((first_conv_kernel<DT>), grid, dim3(256), 0, s, x, w, bias, (char *)out, B, S, So, stride, Cout, Cpad, relu)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool 2x2 stride 2 (ceil_mode: windows clipped at the border)
+// ---------------------------------------------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const char *__restrict__ in, char *__restrict__ out, int B, int H,
+                                                       int W, int Ho, int Wo, int C)
+{
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int ES = elem_traits<DT>::bytes;
+    const int cpr = C / P16;
+    const long long total = (long long)B * Ho * Wo * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        long long pix = i / cpr;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float m[P16];
+#pragma unroll
+        for (int j = 0; j < P16; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hi = 2 * ho + dy, wi = 2 * wo + dx;
+                if (hi < H && wi < W) {
+                    float v[P16];
+                    unpack16<DT>(*(const u32x4 *)(in + ((((size_t)b * H + hi) * W + wi) * C + (size_t)ch * P16) * ES), v);
+#pragma unroll
+                    for (int j = 0; j < P16; ++j) m[j] = fmaxf(m[j], v[j]);
+                }
+            }
+        *(u32x4 *)(out + ((((size_t)b * Ho + ho) * Wo + wo) * C + (size_t)ch * P16) * ES) = pack16<DT>(m);
+    }
+}
+
+int launch_maxpool2(const void *in, void *out, int B, int H, int W, int C, int ceil_mode, int dtype, hipStream_t s)
+{
+    const int Ho = ceil_mode ? (H + 1) / 2 : H / 2, Wo = ceil_mode ? (W + 1) / 2 : W / 2;
+    const int per16 = 16 / dtype_bytes(dtype);
+    if (C % per16) return TDRN_E_UNSUPPORTED;
+    const long long total = (long long)B * Ho * Wo * (C / per16);
+    dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+#define L(DT) hipLaunchKernelGGL((maxpool2_kernel<DT>), grid, dim3(256), 0, s, (const char *)in, (char *)out, B, H, W, Ho, Wo, C)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2Norm: one wavefront per pixel, 16 B per lane per step, wave-wide butterfly reduction.
+// ---------------------------------------------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void l2norm_kernel(const char *__restrict__ in, const float *__restrict__ w,
+                                                     char *__restrict__ out, long long pixels, int C)
+{
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int ES = elem_traits<DT>::bytes;
+    constexpr int MAXS = 8;                      // up to 64*8*8 = 4096 channels (16-bit)
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pix >= pixels) return;
+    const int cpr = C / P16;
+    const char *src = in + (size_t)pix * C * ES;
+    float v[MAXS][P16];
+    float ss = 0.f;
+#pragma unroll
+    for (int st = 0; st < MAXS; ++st) {
+        const int ch = st * 64 + lane;
+        if (ch < cpr) {
+            unpack16<DT>(*(const u32x4 *)(src + (size_t)ch * 16), v[st]);
+#pragma unroll
+            for (int j = 0; j < P16; ++j) ss = fmaf(v[st][j], v[st][j], ss);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float norm = sqrtf(ss) + 1e-10f;
+    char *dst = out + (size_t)pix * C * ES;
+#pragma unroll
+    for (int st = 0; st < MAXS; ++st) {
+        const int ch = st * 64 + lane;
+        if (ch < cpr) {
+            float o[P16];
+#pragma unroll
+            for (int j = 0; j < P16; ++j) o[j] = w[ch * P16 + j] * (v[st][j] / norm);
+            *(u32x4 *)(dst + (size_t)ch * 16) = pack16<DT>(o);
+        }
+    }
+}
+
+int launch_l2norm(const void *in, const float *w, void *out, long long pixels, int C, int dtype, hipStream_t s)
+{
+    const int per16 = 16 / dtype_bytes(dtype);
+    if (C % per16 || C / per16 > 64 * 8) return TDRN_E_UNSUPPORTED;
+    dim3 grid((unsigned)((pixels + 3) / 4));
+#define L(DT) hipLaunchKernelGGL((l2norm_kernel<DT>), grid, dim3(256), 0, s, (const char *)in, w, (char *)out, pixels, C)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise 3x3 (pad 1) + folded BN + ReLU.  Thread = (pixel, 16-B channel chunk).
+// ---------------------------------------------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void dwconv3_kernel(const char *__restrict__ in, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, char *__restrict__ out, int B,
+                                                      int H, int W, int Ho, int Wo, int C, int stride, int relu)
+{
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int ES = elem_traits<DT>::bytes;
+    const int cpr = C / P16;
+    const long long total = (long long)B * Ho * Wo * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        long long pix = i / cpr;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float acc[P16];
+#pragma unroll
+        for (int j = 0; j < P16; ++j) acc[j] = bias[ch * P16 + j];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int hi = ho * stride - 1 + r, wi = wo * stride - 1 + q;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+                    float v[P16];
+                    unpack16<DT>(*(const u32x4 *)(in + ((((size_t)b * H + hi) * W + wi) * C + (size_t)ch * P16) * ES), v);
+                    const float *wt = w + (size_t)(r * 3 + q) * C + ch * P16;
+#pragma unroll
+                    for (int j = 0; j < P16; ++j) acc[j] = fmaf(wt[j], v[j], acc[j]);
+                }
+            }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < P16; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        }
+        *(u32x4 *)(out + ((((size_t)b * Ho + ho) * Wo + wo) * C + (size_t)ch * P16) * ES) = pack16<DT>(acc);
+    }
+}
+
+int launch_dwconv3(const void *in, const float *w, const float *bias, void *out, int B, int H, int W, int C,
+                   int stride, int relu, int dtype, hipStream_t s)
+{
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int per16 = 16 / dtype_bytes(dtype);
+    if (C % per16) return TDRN_E_UNSUPPORTED;
+    const long long total = (long long)B * Ho * Wo * (C / per16);
+    dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+#define L(DT) hipLaunchKernelGGL((dwconv3_kernel<DT>), grid, dim3(256), 0, s, (const char *)in, w, bias, (char *)out, B, H, W, Ho, Wo, C, stride, relu)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax over C (<= 64) classes: rows staged through LDS so that global traffic is
+// coalesced although a row is C*4 bytes; one thread owns one row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                           long long R, int C)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const long long r0 = (long long)blockIdx.x * 256;
+    const int rows = (int)((R - r0) < 256 ? (R - r0) : 256);
+    const int n = rows * C;
+    const int ld = C | 1;                       // odd stride: conflict-free row-per-thread access
+    for (int i = threadIdx.x; i < n; i += 256) sm[(i / C) * ld + (i % C)] = in[r0 * C + i];
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+        float *row = sm + threadIdx.x * ld;
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        float ssum = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float e = expf(row[c] - m);
+            row[c] = e;
+            ssum += e;
+        }
+        for (int c = 0; c < C; ++c) row[c] = row[c] / ssum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) out[r0 * C + i] = sm[(i / C) * ld + (i % C)];
+}
+
+int launch_softmax_rows(const float *in, float *out, long long R, int C, hipStream_t s)
+{
+    if (C < 1 || C > 64) return TDRN_E_UNSUPPORTED;
+    if (R <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((R + 255) / 256));
+    hipLaunchKernelGGL(softmax_rows_kernel, grid, dim3(256), 256 * (size_t)(C | 1) * sizeof(float), s, in, out, R, C);
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// offset convs: off[m][o] = bias[o] + sum_j w[o][j] * loc[m][j]   (n_in = 12, n_out = 18+50)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void offset_conv_kernel(const float *__restrict__ loc, long long loc_bs,
+                                                          long long loc_ps, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ off,
+                                                          int B, int HW, int n_in, int n_out)
+{
+    const long long total = (long long)B * HW * n_out;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % n_out);
+        const long long m = i / n_out;
+        const int b = (int)(m / HW), pix = (int)(m - (long long)b * HW);
+        const float *l = loc + b * loc_bs + pix * loc_ps;
+        float acc = bias ? bias[o] : 0.f;
+        for (int j = 0; j < n_in; ++j) acc = fmaf(w[o * n_in + j], l[j], acc);
+        off[i] = acc;
+    }
+}
+
+int launch_offset_conv(const float *loc, long long loc_bs, long long loc_ps, const float *w, const float *bias,
+                       float *off, int B, int HW, int n_in, int n_out, hipStream_t s)
+{
+    const long long total = (long long)B * HW * n_out;
+    if (total <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+    hipLaunchKernelGGL(offset_conv_kernel, grid, dim3(256), 0, s, loc, loc_bs, loc_ps, w, bias, off, B, HW, n_in, n_out);
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversions (API surfaces are NCHW fp32)
+// ---------------------------------------------------------------------------------------------
+// channel c of group g = c / cpg lands at g*cpg_pad + (c - g*cpg); pad channels are zero
+template <typename DT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in, char *__restrict__ out, int B,
+                                                           int C, int HW, int G, int cpg_pad)
+{
+    constexpr int ES = elem_traits<DT>::bytes;
+    const int Cpad = G * cpg_pad, cpg = C / G;
+    const long long total = (long long)B * HW * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % Cpad);
+        const long long m = i / Cpad;
+        const int b = (int)(m / HW), pix = (int)(m - (long long)b * HW);
+        const int g = cp / cpg_pad, cl = cp - g * cpg_pad;
+        const float v = cl < cpg ? in[((size_t)b * C + g * cpg + cl) * HW + pix] : 0.f;
+        *(DT *)(out + (size_t)i * ES) = from_f32<DT>(v);
+    }
+}
+
+int launch_nchw_to_nhwc_grouped(const float *in, void *out, int B, int C, int HW, int G, int cpg_pad, int dtype,
+                                hipStream_t s)
+{
+    const long long total = (long long)B * HW * G * cpg_pad;
+    if (total <= 0) return TDRN_OK;
+    if (G < 1 || C % G) return TDRN_E_ARG;
+    dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+#define L(DT) hipLaunchKernelGGL((nchw_to_nhwc_kernel<DT>), grid, dim3(256), 0, s, in, (char *)out, B, C, HW, G, cpg_pad)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
+int launch_nchw_to_nhwc(const float *in, void *out, int B, int C, int HW, int Cpad, int dtype, hipStream_t s)
+{
+    return launch_nchw_to_nhwc_grouped(in, out, B, C, HW, 1, Cpad, dtype, s);
+}
+
+// OIHW fp32 -> [Npad][tap][G*cpg_pad] DT (rows >= Cout and pad channels zero)
+template <typename DT>
+__global__ __launch_bounds__(256) void repack_oihw_kernel(const float *__restrict__ w, char *__restrict__ out, int Cout,
+                                                          int Npad, int Cin, int taps, int G, int cpg_pad)
+{
+    constexpr int ES = elem_traits<DT>::bytes;
+    const int Cpad = G * cpg_pad, cpg = Cin / G;
+    const long long total = (long long)Npad * taps * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % Cpad);
+        const long long r = i / Cpad;
+        const int t = (int)(r % taps), co = (int)(r / taps);
+        const int g = cp / cpg_pad, cl = cp - g * cpg_pad;
+        const float v = (co < Cout && cl < cpg) ? w[((size_t)co * Cin + g * cpg + cl) * taps + t] : 0.f;
+        *(DT *)(out + (size_t)i * ES) = from_f32<DT>(v);
+    }
+}
+
+int launch_repack_oihw(const float *w, void *out, int Cout, int Npad, int Cin, int taps, int G, int cpg_pad, int dtype,
+                       hipStream_t s)
+{
+    const long long total = (long long)Npad * taps * G * cpg_pad;
+    if (total <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+#define L(DT) hipLaunchKernelGGL((repack_oihw_kernel<DT>), grid, dim3(256), 0, s, w, (char *)out, Cout, Npad, Cin, taps, G, cpg_pad)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const float *__restrict__ in, long long in_bs,
+                                                               long long in_ps, float *__restrict__ out, int B, int C,
+                                                               int HW)
+{
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const long long bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        out[i] = in[b * in_bs + pix * in_ps + c];
+    }
+}
+
+int launch_nhwc_to_nchw_f32(const float *in, long long in_bs, long long in_ps, float *out, int B, int C, int HW,
+                            hipStream_t s)
+{
+    const long long total = (long long)B * C * HW;
+    if (total <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, grid, dim3(256), 0, s, in, in_bs, in_ps, out, B, C, HW);
+    return hip_status(hipGetLastError());
+}
+
+int launch_fill_zero(void *p, size_t bytes, hipStream_t s)
+{
+    return hip_status(hipMemsetAsync(p, 0, bytes, s));
+}
+
+}  // namespace tdrn

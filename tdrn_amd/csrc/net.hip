@@ -1,0 +1,898 @@
+// net.hip -- host-side layer plan, weight packing (BatchNorm folding, OIHW -> [Cout][tap][Cin])
+// and the forward executor for the reference's model families.  No device allocation: the weight
+// blob and the activation workspace are caller-owned (tdrn_hip.h).
+//
+//   model/dualrefinedet_vggbn.py:10-206      build_drn_vgg()
+//   model/dualrefinedet_mobilenet.py:8-199   build_drn_mobilenet()
+//   model/ssd4scale_mobile.py:9-140          build_ssd4scale_mobile()
+//   model/refinedet_vgg.py:27-219            build_refinedet_vgg()
+//   model/ssd4scale_vgg.py                   build_ssd4scale_vgg()
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace tdrn {
+
+unsigned short host_f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+unsigned short host_f32_to_f16(float f)
+{
+    _Float16 h = (_Float16)f;
+    unsigned short r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+namespace {
+
+enum OpKind { OP_FIRST, OP_CONV, OP_POOL, OP_L2NORM, OP_DW, OP_OFFSET, OP_DEFORM, OP_SOFTMAX, OP_OFF_OUT, OP_LOC_OUT,
+              OP_REFLOC_IN };
+enum OutKind { OUT_TENSOR = 0, OUT_ARM_LOC = 1, OUT_ODM_LOC = 2, OUT_CONF = 3 };
+
+struct Tensor { int C, Cpad, H, W; bool f32; size_t off; /* bytes per sample from workspace start */ };
+struct ParamSpec { std::string name; std::vector<int64_t> shape; };
+
+struct Op {
+    OpKind kind;
+    int in = -1, out = -1, res = -1;
+    int Cin = 0, Cout = 0, Npad = 0, k = 1, stride = 1, pad = 0, dil = 1, relu = 0, phases = 1, ceil = 0;
+    int out_kind = OUT_TENSOR, scale = 0, hw = 0;        // head ops: which pyramid level
+    int G = 1, n_branches = 1, k2 = 0, pad2 = 0;          // deform
+    int off_t = -1, off_c0[2] = {0, 0}, off_n = 0;        // offset tensor (fp32 NHWC), channel starts
+    int loc_src = OUT_ARM_LOC;                            // OP_OFFSET input: ARM loc view or a ref_loc tensor
+    std::string w, b, bn, w2, b2;                          // parameter names (w2/b2: second source)
+    size_t w_off = 0, b_off = 0, w2_off = 0;               // blob offsets
+    double flops = 0, bytes = 0;                           // algorithmic, per sample
+    int stat = 0;
+};
+
+const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
+                            "deform_gemm_mfma", "softmax21", "layout"};
+enum { ST_CONV, ST_FIRST, ST_POOL, ST_L2, ST_DW, ST_OFFSET, ST_DEFORM, ST_SOFTMAX, ST_LAYOUT, ST_COUNT };
+
+}  // namespace
+}  // namespace tdrn
+
+using namespace tdrn;
+
+struct tdrn_net {
+    tdrn_net_config cfg{};
+    int es = 2;
+    std::vector<Tensor> tensors;
+    std::vector<ParamSpec> params;
+    std::map<std::string, size_t> param_index;
+    std::map<std::string, std::vector<float>> staged;
+    std::vector<Op> ops;
+    size_t ws_per_sample = 0, blob_bytes = kZeroPageBytes;
+    int P = 0, fm[4] = {0, 0, 0, 0}, scale_off[5] = {0, 0, 0, 0, 0};
+    bool weights_ready = false;
+    bool profile = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_stat;
+    tdrn_kernel_stat stats[ST_COUNT];
+    int last_batch = 0;
+
+    // ---- plan building --------------------------------------------------------------------
+    int T(int C, int H, int W, bool f32 = false)
+    {
+        Tensor t;
+        t.C = C; t.H = H; t.W = W; t.f32 = f32;
+        t.Cpad = f32 ? C : (int)align_up((size_t)C, kChanPad);
+        t.off = ws_per_sample;
+        ws_per_sample += align_up((size_t)t.Cpad * H * W * (f32 ? 4 : es), 256);
+        tensors.push_back(t);
+        return (int)tensors.size() - 1;
+    }
+    void P_(const std::string &name, std::vector<int64_t> shape)
+    {
+        param_index[name] = params.size();
+        params.push_back(ParamSpec{name, std::move(shape)});
+    }
+    void bn_params(const std::string &bn, int C)
+    {
+        P_(bn + ".weight", {C}); P_(bn + ".bias", {C}); P_(bn + ".running_mean", {C}); P_(bn + ".running_var", {C});
+    }
+    size_t blob(size_t bytes)
+    {
+        const size_t o = blob_bytes;
+        blob_bytes += align_up(bytes, 256);
+        return o;
+    }
+
+    // first conv (Cin = 3), BN folded
+    int first_conv(const std::string &w, bool bias, const std::string &bn, int Cout, int stride, int S)
+    {
+        const int So = (S + 2 - 3) / stride + 1;
+        Op o; o.kind = OP_FIRST; o.stat = ST_FIRST;
+        o.Cin = 3; o.Cout = Cout; o.stride = stride; o.relu = 1; o.hw = S;
+        o.w = w; o.bn = bn;
+        P_(w + ".weight", {Cout, 3, 3, 3});
+        if (bias) { o.b = w; P_(w + ".bias", {Cout}); }
+        if (!bn.empty()) bn_params(bn, Cout);
+        o.out = T(Cout, So, So);
+        o.w_off = blob((size_t)Cout * 27 * 4);
+        o.b_off = blob((size_t)tensors[o.out].Cpad * 4);
+        o.flops = 2.0 * So * So * Cout * 27;
+        o.bytes = 3.0 * S * S * 4 + (double)So * So * tensors[o.out].Cpad * es;
+        ops.push_back(o);
+        return o.out;
+    }
+
+    // dense conv -> NHWC tensor (out_kind == OUT_TENSOR) or fp32 head output view
+    int conv(int in, const std::string &w, bool bias, const std::string &bn, int Cout, int k, int stride, int pad, int dil,
+             int relu, int res = -1, int out_kind = OUT_TENSOR, int scale = 0, const std::string &w2 = "", int k2 = 0)
+    {
+        const Tensor ti = tensors[in];
+        Op o; o.kind = OP_CONV; o.stat = ST_CONV;
+        o.in = in; o.res = res; o.Cin = ti.Cpad; o.Cout = Cout; o.k = k; o.stride = stride; o.pad = pad; o.dil = dil;
+        o.relu = relu; o.out_kind = out_kind; o.scale = scale; o.w = w; o.bn = bn; o.w2 = w2; o.k2 = k2;
+        const int Ho = (ti.H + 2 * pad - (dil * (k - 1) + 1)) / stride + 1;
+        const int Wo = (ti.W + 2 * pad - (dil * (k - 1) + 1)) / stride + 1;
+        P_(w + ".weight", {Cout, ti.C, k, k});
+        if (bias) { o.b = w; P_(w + ".bias", {Cout}); }
+        if (!bn.empty()) bn_params(bn, Cout);
+        if (!w2.empty()) {   // a second, smaller conv merged into the same taps (refinedet multihead)
+            P_(w2 + ".weight", {Cout, ti.C, k2, k2});
+            if (bias) { o.b2 = w2; P_(w2 + ".bias", {Cout}); }
+        }
+        if (out_kind == OUT_TENSOR) {
+            o.out = T(Cout, Ho, Wo);
+            o.Cout = tensors[o.out].Cpad;            // pad channels are written as zeros
+        }
+        o.Npad = conv_n_pad(o.Cout);
+        o.hw = Ho * 65536 + Wo;
+        o.w_off = blob((size_t)o.Npad * k * k * o.Cin * es);
+        o.b_off = blob((size_t)o.Npad * 4);
+        o.flops = 2.0 * Ho * Wo * Cout * (double)k * k * ti.C;
+        o.bytes = (double)ti.H * ti.W * ti.Cpad * es + (double)Ho * Wo * o.Cout * (out_kind == OUT_TENSOR ? es : 4) +
+                  (res >= 0 ? (double)Ho * Wo * o.Cout * es : 0.0);
+        ops.push_back(o);
+        return o.out;
+    }
+
+    // ConvTranspose2d(k=2, s=2) + residual + ReLU as four phase GEMMs
+    int conv_transpose2(int in, const std::string &w, bool bias, int Cout, int res, int relu)
+    {
+        const Tensor ti = tensors[in];
+        Op o; o.kind = OP_CONV; o.stat = ST_CONV;
+        o.in = in; o.res = res; o.Cin = ti.Cpad; o.k = 1; o.relu = relu; o.phases = 4; o.w = w;
+        P_(w + ".weight", {ti.C, Cout, 2, 2});
+        if (bias) { o.b = w; P_(w + ".bias", {Cout}); }
+        o.out = T(Cout, ti.H * 2, ti.W * 2);
+        o.Cout = tensors[o.out].Cpad;
+        o.Npad = conv_n_pad(o.Cout);
+        o.hw = ti.H * 65536 + ti.W;
+        o.w_off = blob((size_t)4 * o.Npad * o.Cin * es);
+        o.b_off = blob((size_t)o.Npad * 4);
+        o.flops = 2.0 * 4 * ti.H * ti.W * (double)Cout * ti.C;
+        o.bytes = (double)ti.H * ti.W * ti.Cpad * es + 2.0 * 4 * ti.H * ti.W * o.Cout * es;
+        ops.push_back(o);
+        return o.out;
+    }
+
+    int pool(int in, int ceil_mode)
+    {
+        const Tensor ti = tensors[in];
+        Op o; o.kind = OP_POOL; o.stat = ST_POOL; o.in = in; o.ceil = ceil_mode;
+        const int Ho = ceil_mode ? (ti.H + 1) / 2 : ti.H / 2, Wo = ceil_mode ? (ti.W + 1) / 2 : ti.W / 2;
+        o.out = T(ti.C, Ho, Wo);
+        o.bytes = ((double)ti.H * ti.W + (double)Ho * Wo) * ti.Cpad * es;
+        ops.push_back(o);
+        return o.out;
+    }
+
+    int l2norm(int in, const std::string &name)
+    {
+        const Tensor ti = tensors[in];
+        Op o; o.kind = OP_L2NORM; o.stat = ST_L2; o.in = in; o.w = name;
+        P_(name + ".weight", {ti.C});
+        o.out = T(ti.C, ti.H, ti.W);
+        o.w_off = blob((size_t)ti.Cpad * 4);
+        o.bytes = 2.0 * ti.H * ti.W * ti.Cpad * es;
+        ops.push_back(o);
+        return o.out;
+    }
+
+    int dwconv(int in, const std::string &w, const std::string &bn, int stride)
+    {
+        const Tensor ti = tensors[in];
+        Op o; o.kind = OP_DW; o.stat = ST_DW; o.in = in; o.stride = stride; o.relu = 1; o.w = w; o.bn = bn;
+        P_(w + ".weight", {ti.C, 1, 3, 3});
+        bn_params(bn, ti.C);
+        const int Ho = (ti.H + 2 - 3) / stride + 1, Wo = (ti.W + 2 - 3) / stride + 1;
+        o.out = T(ti.C, Ho, Wo);
+        o.w_off = blob((size_t)9 * ti.Cpad * 4);
+        o.b_off = blob((size_t)ti.Cpad * 4);
+        o.flops = 2.0 * Ho * Wo * ti.C * 9;
+        o.bytes = ((double)ti.H * ti.W + (double)Ho * Wo) * ti.Cpad * es;
+        ops.push_back(o);
+        return o.out;
+    }
+    // conv_dw block, model/networks.py:736-745
+    int conv_dw(int in, const std::string &name, int Cout, int stride)
+    {
+        const int d = dwconv(in, name + ".0", name + ".1", stride);
+        return conv(d, name + ".3", false, name + ".4", Cout, 1, 1, 0, 1, 1);
+    }
+
+    // 1x1 offset convs on the 12-channel loc map of pyramid level `scale`
+    int offset_conv(int scale, int H, int W, const std::string &w1, const std::string &w2, bool bias, int n1, int n2,
+                    int loc_src, int ref_tensor = -1)
+    {
+        Op o; o.kind = OP_OFFSET; o.stat = ST_OFFSET; o.scale = scale; o.hw = H * W; o.w = w1; o.w2 = w2;
+        o.loc_src = loc_src; o.in = ref_tensor;
+        P_(w1 + ".weight", {n1, 12, 1, 1});
+        if (bias) { o.b = w1; P_(w1 + ".bias", {n1}); }
+        if (!w2.empty()) {
+            P_(w2 + ".weight", {n2, 12, 1, 1});
+            if (bias) { o.b2 = w2; P_(w2 + ".bias", {n2}); }
+        } else {
+            n2 = 0;
+        }
+        o.off_n = n1 + n2; o.off_c0[0] = 0; o.off_c0[1] = n1;
+        o.out = T(o.off_n, H, W, true);
+        o.w_off = blob((size_t)o.off_n * 12 * 4);
+        o.b_off = blob((size_t)o.off_n * 4);
+        o.flops = 2.0 * H * W * o.off_n * 12;
+        o.bytes = (double)H * W * (12 + o.off_n) * 4;
+        ops.push_back(o);
+        return o.out;
+    }
+
+    // fused deformable heads of one pyramid level: [loc ; conf] rows, 1 or 2 branches
+    void deform_heads(int in, int off_t, int scale, int G, const std::string &loc1, const std::string &conf1,
+                      const std::string &loc2, const std::string &conf2, int off_c1, int out_loc_kind)
+    {
+        const Tensor ti = tensors[in];
+        const int nc3 = 3 * cfg.num_classes;
+        Op o; o.kind = OP_DEFORM; o.stat = ST_DEFORM; o.in = in; o.off_t = off_t; o.scale = scale; o.G = G;
+        o.Cin = ti.Cpad; o.Cout = 12 + nc3; o.Npad = deform_n_pad(o.Cout);
+        o.k = 3; o.pad = 1; o.w = loc1; o.b = conf1; o.out_kind = out_loc_kind;
+        P_(loc1 + ".weight", {12, ti.C, 3, 3});
+        P_(conf1 + ".weight", {nc3, ti.C, 3, 3});
+        o.w_off = blob((size_t)o.Npad * 9 * o.Cin * es);
+        o.off_c0[0] = 0;
+        double taps = 9;
+        if (!loc2.empty()) {
+            o.n_branches = 2; o.k2 = 5; o.pad2 = 2; o.w2 = loc2; o.b2 = conf2; o.off_c0[1] = off_c1;
+            P_(loc2 + ".weight", {12, ti.C, 5, 5});
+            P_(conf2 + ".weight", {nc3, ti.C, 5, 5});
+            o.w2_off = blob((size_t)o.Npad * 25 * o.Cin * es);
+            taps += 25;
+        }
+        o.hw = ti.H * 65536 + ti.W;
+        o.flops = 2.0 * ti.H * ti.W * o.Cout * taps * ti.C;
+        o.bytes = (double)ti.H * ti.W * (ti.Cpad * es + (o.Cout + 2 * taps * G) * 4);
+        ops.push_back(o);
+    }
+
+    void softmax_op()
+    {
+        Op o; o.kind = OP_SOFTMAX; o.stat = ST_SOFTMAX;
+        o.bytes = 2.0 * P * cfg.num_classes * 4;
+        ops.push_back(o);
+    }
+    void offsets_out(int scale, int off_t, int n) { Op o; o.kind = OP_OFF_OUT; o.stat = ST_LAYOUT; o.scale = scale; o.in = off_t; o.Cout = n; ops.push_back(o); }
+    void loc_maps_out(int scale) { Op o; o.kind = OP_LOC_OUT; o.stat = ST_LAYOUT; o.scale = scale; ops.push_back(o); }
+    int ref_loc_in(int scale, int H, int W)
+    {
+        Op o; o.kind = OP_REFLOC_IN; o.stat = ST_LAYOUT; o.scale = scale; o.hw = H * W;
+        o.out = T(12, H, W, true);
+        ops.push_back(o);
+        return o.out;
+    }
+
+    void set_pyramid(int s0)
+    {
+        fm[0] = s0; fm[1] = s0 / 2; fm[2] = s0 / 4; fm[3] = s0 / 8;
+        scale_off[0] = 0;
+        for (int i = 0; i < 4; ++i) scale_off[i + 1] = scale_off[i] + fm[i] * fm[i] * 3;
+        P = scale_off[4];
+    }
+
+    // ---- model families ---------------------------------------------------------------------
+    // VGG16 trunk (model/networks.py:136-163).  Returns conv4_3, conv5_3, fc7 tensors (post-ReLU).
+    void vgg_trunk(int S, bool bn, int c7, int &c43, int &c53, int &fc7)
+    {
+        static const int cfgv[] = {64, 64, -1, 128, 128, -1, 256, 256, 256, -2, 512, 512, 512, -1, 512, 512, 512};
+        int idx = 0, x = -1, nconv = 0;
+        for (int v : cfgv) {
+            if (v < 0) {
+                x = pool(x, v == -2);
+                idx += 1;
+                continue;
+            }
+            const std::string name = "backbone." + std::to_string(idx);
+            const std::string bnn = bn ? "backbone." + std::to_string(idx + 1) : "";
+            if (x < 0) x = first_conv(name, true, bnn, v, 1, S);
+            else x = conv(x, name, true, bnn, v, 3, 1, 1, 1, 1);
+            idx += bn ? 3 : 2;
+            ++nconv;
+            if (nconv == 10) c43 = x;
+            if (nconv == 13) c53 = x;
+        }
+        x = pool(x, 0);   // pool5_ds
+        idx += 1;
+        x = conv(x, "backbone." + std::to_string(idx), true, bn ? "backbone." + std::to_string(idx + 1) : "", 1024, 3, 1, 6, 6, 1);
+        idx += bn ? 3 : 2;
+        fc7 = conv(x, "backbone." + std::to_string(idx), true, bn ? "backbone." + std::to_string(idx + 1) : "", c7, 1, 1, 0, 1, 1);
+    }
+
+    // TCB / FPN (dualrefinedet_vggbn.py:30-34,97-114,166-178).  Returns the 4 ODM sources.
+    void tcb(const int src[4], bool bias, int odm[4])
+    {
+        int x = conv(src[3], "last_layer_trans.0", bias, "", 256, 3, 1, 1, 1, 1);
+        x = conv(x, "last_layer_trans.2", bias, "", 256, 3, 1, 1, 1, 0);
+        x = conv(x, "last_layer_trans.3", bias, "", 256, 3, 1, 1, 1, 0);
+        odm[3] = x;
+        int t[3];
+        for (int s = 0; s < 3; ++s) {
+            const std::string n = "trans_layers." + std::to_string(s);
+            const int a = conv(src[s], n + ".0", bias, "", 256, 3, 1, 1, 1, 1);
+            t[s] = conv(a, n + ".2", bias, "", 256, 3, 1, 1, 1, 0);
+        }
+        for (int i = 0; i < 3; ++i) {
+            const int lvl = 2 - i;
+            const int u = conv_transpose2(x, "up_layers." + std::to_string(i), bias, 256, t[lvl], 1);
+            x = conv(u, "latent_layers." + std::to_string(i), bias, "", 256, 3, 1, 1, 1, 1);
+            odm[lvl] = x;
+        }
+    }
+
+    void drn_heads(const int src[4], const int odm[4], bool bias)
+    {
+        int off_t[4];
+        for (int s = 0; s < 4; ++s) {
+            const std::string ss = std::to_string(s);
+            conv(src[s], "arm_loc." + ss, bias, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
+            off_t[s] = offset_conv(s, fm[s], fm[s], "offset." + ss, cfg.multihead ? "offset2." + ss : "", bias,
+                                   cfg.def_groups * 18, cfg.def_groups * 50, OUT_ARM_LOC);
+            offsets_out(s, off_t[s], cfg.def_groups * 18);
+        }
+        for (int s = 0; s < 4; ++s) {
+            const std::string ss = std::to_string(s);
+            deform_heads(odm[s], off_t[s], s, cfg.def_groups, "odm_loc." + ss, "odm_conf." + ss,
+                         cfg.multihead ? "odm_loc_2." + ss : "", cfg.multihead ? "odm_conf_2." + ss : "",
+                         cfg.def_groups * 18, OUT_ODM_LOC);
+        }
+        if (cfg.test_phase) softmax_op();
+    }
+
+    int build_drn_vgg()
+    {
+        const int S = cfg.size;
+        set_pyramid(S / 8);
+        int c43, c53, fc7;
+        vgg_trunk(S, cfg.bn != 0, cfg.c7_channel, c43, c53, fc7);
+        int src[4], odm[4];
+        src[0] = l2norm(c43, "L2Norm_4_3");
+        src[1] = l2norm(c53, "L2Norm_5_3");
+        src[2] = fc7;
+        if (cfg.bn) {
+            const int e = conv(fc7, "extras.0", true, "extras.1", 256, 1, 1, 0, 1, 1);
+            src[3] = conv(e, "extras.3", true, "extras.4", 512, 3, 2, 1, 1, 1);
+        } else {
+            const int e = conv(fc7, "extras.0", true, "", 256, 1, 1, 0, 1, 1);
+            src[3] = conv(e, "extras.2", true, "", 512, 3, 2, 1, 1, 1);
+        }
+        tcb(src, true, odm);
+        drn_heads(src, odm, true);
+        return TDRN_OK;
+    }
+
+    // MobileNet-v1 trunk shared by dualrefinedet_mobilenet.py:19-48 and ssd4scale_mobile.py:20-50
+    void mobilenet_trunk(int S, int c7, bool extras_bias, int src_raw[4])
+    {
+        static const int couts[] = {64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 0};
+        static const int strides[] = {1, 2, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 1};
+        int x = first_conv("backbone.0.0", false, "backbone.0.1", 32, 2, S);
+        for (int i = 0; i < 13; ++i) {
+            x = conv_dw(x, "backbone." + std::to_string(i + 1), i == 12 ? c7 : couts[i], strides[i]);
+            if (i + 1 == 11) src_raw[0] = x;
+        }
+        src_raw[1] = x;
+        for (int k = 0; k < 2; ++k) {
+            const std::string n = "extras." + std::to_string(k);
+            x = conv(x, n + ".0", extras_bias, n + ".1", 256, 1, 1, 0, 1, 1);
+            x = conv_dw(x, n + ".3", 512, 2);
+            src_raw[2 + k] = x;
+        }
+    }
+
+    int build_drn_mobilenet()
+    {
+        set_pyramid(cfg.size / 8);
+        int raw[4], src[4], odm[4];
+        mobilenet_trunk(cfg.size, 1024, true, raw);
+        src[0] = l2norm(raw[0], "L2Norm_4_3");
+        src[1] = l2norm(raw[1], "L2Norm_5_3");
+        src[2] = raw[2];
+        src[3] = raw[3];
+        tcb(src, false, odm);
+        drn_heads(src, odm, false);
+        return TDRN_OK;
+    }
+
+    int build_ssd4scale(bool mobile)
+    {
+        set_pyramid(cfg.size / 8);
+        int src[4];
+        if (mobile) {
+            int raw[4];
+            mobilenet_trunk(cfg.size, cfg.c7_channel, true, raw);
+            src[0] = l2norm(raw[0], "L2Norm_4_3");
+            src[1] = l2norm(raw[1], "L2Norm_5_3");
+            src[2] = raw[2];
+            src[3] = raw[3];
+        } else {
+            return TDRN_E_UNSUPPORTED;
+        }
+        const int nc3 = 3 * cfg.num_classes;
+        for (int s = 0; s < 4; ++s) {
+            const std::string ss = std::to_string(s);
+            if (cfg.deform) {
+                const int rl = ref_loc_in(s, fm[s], fm[s]);
+                const int ot = offset_conv(s, fm[s], fm[s], "offset." + ss, "", true, 8 * 18, 0, -1, rl);
+                offsets_out(s, ot, 8 * 18);
+                deform_heads(src[s], ot, s, 8, "arm_loc." + ss, "arm_conf." + ss, "", "", 0, OUT_ARM_LOC);
+            } else {
+                conv(src[s], "arm_loc." + ss, true, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
+                conv(src[s], "arm_conf." + ss, true, "", nc3, 3, 1, 1, 1, 0, -1, OUT_CONF, s);
+                loc_maps_out(s);
+            }
+        }
+        if (cfg.test_phase) softmax_op();
+        return TDRN_OK;
+    }
+
+    int build()
+    {
+        es = dtype_bytes(cfg.dtype);
+        if (cfg.size != 320 && cfg.size != 512) return TDRN_E_ARG;
+        if (cfg.num_classes < 2 || cfg.num_classes > 21 * 4) return TDRN_E_ARG;
+        if (cfg.dtype < 0 || cfg.dtype > 2) return TDRN_E_ARG;
+        if (cfg.def_groups < 1) return TDRN_E_ARG;
+        switch (cfg.model) {
+            case TDRN_DRN_VGGBN: return build_drn_vgg();
+            case TDRN_DRN_MOBILENET: return build_drn_mobilenet();
+            case TDRN_SSD4SCALE_MOBILE: return build_ssd4scale(true);
+            default: return TDRN_E_UNSUPPORTED;
+        }
+    }
+
+    // ---- weight packing -----------------------------------------------------------------------
+    const std::vector<float> *get(const std::string &name) const
+    {
+        auto it = staged.find(name);
+        return it == staged.end() ? nullptr : &it->second;
+    }
+    void put_elem(char *dst, size_t idx, float v) const
+    {
+        if (cfg.dtype == TDRN_F32) ((float *)dst)[idx] = v;
+        else if (cfg.dtype == TDRN_BF16) ((unsigned short *)dst)[idx] = host_f32_to_bf16(v);
+        else ((unsigned short *)dst)[idx] = host_f32_to_f16(v);
+    }
+    // y = scale*conv + shift  with BatchNorm (eps 1e-5, running stats) folded in double
+    int fold(const Op &o, int Cout, std::vector<double> &scale, std::vector<double> &shift) const
+    {
+        scale.assign(Cout, 1.0);
+        shift.assign(Cout, 0.0);
+        if (!o.b.empty() && o.kind != OP_DEFORM) {
+            const auto *b = get(o.b + ".bias");
+            if (!b) return TDRN_E_PARAM;
+            for (int c = 0; c < Cout; ++c) shift[c] = (*b)[c];
+        }
+        if (!o.bn.empty()) {
+            const auto *g = get(o.bn + ".weight"), *be = get(o.bn + ".bias"), *mu = get(o.bn + ".running_mean"),
+                       *var = get(o.bn + ".running_var");
+            if (!g || !be || !mu || !var) return TDRN_E_PARAM;
+            for (int c = 0; c < Cout; ++c) {
+                const double s = (double)(*g)[c] / std::sqrt((double)(*var)[c] + 1e-5);
+                scale[c] = s;
+                shift[c] = (shift[c] - (double)(*mu)[c]) * s + (double)(*be)[c];
+            }
+        }
+        return TDRN_OK;
+    }
+
+    int pack(std::vector<char> &host) const
+    {
+        host.assign(blob_bytes, 0);
+        for (const Op &o : ops) {
+            std::vector<double> sc, sh;
+            switch (o.kind) {
+                case OP_FIRST: {
+                    const auto *w = get(o.w + ".weight");
+                    if (!w) return TDRN_E_PARAM;
+                    TDRN_TRY(fold(o, o.Cout, sc, sh));
+                    float *dw = (float *)(host.data() + o.w_off), *db = (float *)(host.data() + o.b_off);
+                    for (int c = 0; c < o.Cout; ++c) {
+                        for (int k = 0; k < 27; ++k) dw[c * 27 + k] = (float)((double)(*w)[(size_t)c * 27 + k] * sc[c]);
+                        db[c] = (float)sh[c];
+                    }
+                    break;
+                }
+                case OP_CONV: {
+                    const auto *w = get(o.w + ".weight");
+                    if (!w) return TDRN_E_PARAM;
+                    const Tensor &ti = tensors[o.in];
+                    const int Creal = ti.C, Cin = o.Cin, k = o.k, taps = k * k;
+                    char *dw = host.data() + o.w_off;
+                    float *db = (float *)(host.data() + o.b_off);
+                    if (o.phases == 4) {
+                        // ConvTranspose2d weight (Cin, Cout, 2, 2): slab(i,j)[co][ci] = W[ci][co][i][j]
+                        const int Cout = (int)params[param_index.at(o.w + ".weight")].shape[1];
+                        for (int ph = 0; ph < 4; ++ph)
+                            for (int co = 0; co < Cout; ++co)
+                                for (int ci = 0; ci < Creal; ++ci)
+                                    put_elem(dw, ((size_t)ph * o.Npad + co) * Cin + ci,
+                                             (*w)[(((size_t)ci * Cout + co) * 2 + (ph >> 1)) * 2 + (ph & 1)]);
+                        if (!o.b.empty()) {
+                            const auto *b = get(o.b + ".bias");
+                            if (!b) return TDRN_E_PARAM;
+                            for (int co = 0; co < Cout; ++co) db[co] = (*b)[co];
+                        }
+                        break;
+                    }
+                    const int Cout = (int)params[param_index.at(o.w + ".weight")].shape[0];
+                    TDRN_TRY(fold(o, Cout, sc, sh));
+                    for (int co = 0; co < Cout; ++co) {
+                        for (int t = 0; t < taps; ++t)
+                            for (int ci = 0; ci < Creal; ++ci)
+                                put_elem(dw, ((size_t)co * taps + t) * Cin + ci,
+                                         (float)((double)(*w)[((size_t)co * Creal + ci) * taps + t] * sc[co]));
+                        db[co] = (float)sh[co];
+                    }
+                    if (!o.w2.empty()) {   // merge a centred k2 x k2 conv (same stride/dilation) into the k x k taps
+                        const auto *w2 = get(o.w2 + ".weight");
+                        if (!w2) return TDRN_E_PARAM;
+                        const int k2 = o.k2, d = (k - k2) / 2;
+                        std::vector<float> merged((size_t)Cout * taps * Creal, 0.f);
+                        for (int co = 0; co < Cout; ++co)
+                            for (int ci = 0; ci < Creal; ++ci) {
+                                for (int t = 0; t < taps; ++t)
+                                    merged[((size_t)co * taps + t) * Creal + ci] = (*w)[((size_t)co * Creal + ci) * taps + t];
+                                for (int r = 0; r < k2; ++r)
+                                    for (int q = 0; q < k2; ++q)
+                                        merged[((size_t)co * taps + (r + d) * k + (q + d)) * Creal + ci] +=
+                                            (*w2)[((size_t)co * Creal + ci) * k2 * k2 + r * k2 + q];
+                            }
+                        for (int co = 0; co < Cout; ++co)
+                            for (int t = 0; t < taps; ++t)
+                                for (int ci = 0; ci < Creal; ++ci)
+                                    put_elem(dw, ((size_t)co * taps + t) * Cin + ci, merged[((size_t)co * taps + t) * Creal + ci]);
+                        if (!o.b2.empty()) {
+                            const auto *b2 = get(o.b2 + ".bias");
+                            if (!b2) return TDRN_E_PARAM;
+                            for (int co = 0; co < Cout; ++co) db[co] += (*b2)[co];
+                        }
+                    }
+                    break;
+                }
+                case OP_L2NORM: {
+                    const auto *w = get(o.w + ".weight");
+                    if (!w) return TDRN_E_PARAM;
+                    memcpy(host.data() + o.w_off, w->data(), w->size() * 4);
+                    break;
+                }
+                case OP_DW: {
+                    const auto *w = get(o.w + ".weight");
+                    if (!w) return TDRN_E_PARAM;
+                    const Tensor &ti = tensors[o.in];
+                    TDRN_TRY(fold(o, ti.C, sc, sh));
+                    float *dw = (float *)(host.data() + o.w_off), *db = (float *)(host.data() + o.b_off);
+                    for (int c = 0; c < ti.C; ++c) {
+                        for (int t = 0; t < 9; ++t) dw[(size_t)t * ti.Cpad + c] = (float)((double)(*w)[(size_t)c * 9 + t] * sc[c]);
+                        db[c] = (float)sh[c];
+                    }
+                    break;
+                }
+                case OP_OFFSET: {
+                    float *dw = (float *)(host.data() + o.w_off), *db = (float *)(host.data() + o.b_off);
+                    const std::string *names[2] = {&o.w, &o.w2};
+                    const std::string *bnames[2] = {&o.b, &o.b2};
+                    int row = 0;
+                    for (int i = 0; i < 2; ++i) {
+                        if (names[i]->empty()) continue;
+                        const auto *w = get(*names[i] + ".weight");
+                        if (!w) return TDRN_E_PARAM;
+                        const int n = (int)(w->size() / 12);
+                        memcpy(dw + (size_t)row * 12, w->data(), w->size() * 4);
+                        if (!bnames[i]->empty()) {
+                            const auto *b = get(*bnames[i] + ".bias");
+                            if (!b) return TDRN_E_PARAM;
+                            memcpy(db + row, b->data(), b->size() * 4);
+                        }
+                        row += n;
+                    }
+                    break;
+                }
+                case OP_DEFORM: {
+                    const Tensor &ti = tensors[o.in];
+                    const int nc3 = 3 * cfg.num_classes;
+                    for (int br = 0; br < o.n_branches; ++br) {
+                        const std::string &ln = br ? o.w2 : o.w, &cn = br ? o.b2 : o.b;
+                        const auto *wl = get(ln + ".weight"), *wc = get(cn + ".weight");
+                        if (!wl || !wc) return TDRN_E_PARAM;
+                        const int k = br ? o.k2 : o.k, taps = k * k;
+                        char *dw = host.data() + (br ? o.w2_off : o.w_off);
+                        for (int co = 0; co < 12 + nc3; ++co) {
+                            const std::vector<float> &src = co < 12 ? *wl : *wc;
+                            const int cs = co < 12 ? co : co - 12;
+                            for (int t = 0; t < taps; ++t)
+                                for (int ci = 0; ci < ti.C; ++ci)
+                                    put_elem(dw, ((size_t)co * taps + t) * o.Cin + ci, src[((size_t)cs * ti.C + ci) * taps + t]);
+                        }
+                    }
+                    break;
+                }
+                default: break;
+            }
+        }
+        return TDRN_OK;
+    }
+
+    // ---- forward ------------------------------------------------------------------------------
+    char *tptr(void *ws, int id, int B) const { return (char *)ws + tensors[id].off * (size_t)B; }
+
+    int forward(const void *blob, void *ws, size_t ws_bytes, const tdrn_net_io *io, hipStream_t s)
+    {
+        if (!weights_ready) return TDRN_E_STATE;
+        if (!blob || !ws || !io || !io->x || io->batch <= 0) return TDRN_E_ARG;
+        const int B = io->batch;
+        if (ws_bytes < ws_per_sample * (size_t)B) return TDRN_E_WORKSPACE;
+        if (!io->arm_loc || !io->conf) return TDRN_E_ARG;
+        const bool is_drn = cfg.model == TDRN_DRN_VGGBN || cfg.model == TDRN_DRN_MOBILENET || cfg.model == TDRN_REFINEDET_VGG;
+        if (is_drn && !io->odm_loc) return TDRN_E_ARG;
+        const char *wb = (const char *)blob;
+        const int C = cfg.num_classes;
+        last_batch = B;
+        size_t evi = 0;
+        if (profile && ev.size() < 2 * ops.size()) {
+            const size_t old = ev.size();
+            ev.resize(2 * ops.size());
+            for (size_t i = old; i < ev.size(); ++i) TDRN_HIP_TRY(hipEventCreate(&ev[i]));
+        }
+        ev_stat.clear();
+        for (const Op &o : ops) {
+            bool skip = false;
+            if (o.kind == OP_OFF_OUT && !io->offsets[o.scale]) skip = true;
+            if (o.kind == OP_LOC_OUT && !io->loc_maps[o.scale]) skip = true;
+            if (skip) continue;
+            if (profile) { TDRN_HIP_TRY(hipEventRecord(ev[evi], s)); }
+            int rc = TDRN_OK;
+            switch (o.kind) {
+                case OP_FIRST:
+                    rc = launch_first_conv(io->x, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off), tptr(ws, o.out, B),
+                                           B, o.hw, o.stride, o.Cout, tensors[o.out].Cpad, o.relu, cfg.dtype, s);
+                    break;
+                case OP_CONV: {
+                    const Tensor &ti = tensors[o.in];
+                    ConvArgs a;
+                    a.in = tptr(ws, o.in, B); a.w = wb + o.w_off; a.bias = (const float *)(wb + o.b_off); a.zero_page = wb;
+                    a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
+                    a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
+                    a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
+                    if (o.out_kind == OUT_TENSOR) {
+                        const Tensor &to = tensors[o.out];
+                        a.out = tptr(ws, o.out, B);
+                        if (o.res >= 0) a.res = tptr(ws, o.res, B);
+                        a.o_cs = to.Cpad;
+                        if (o.phases == 4) {
+                            a.o_bs = (long long)to.H * to.W * to.Cpad; a.o_rs = 2ll * to.W * to.Cpad; a.o_cs = 2ll * to.Cpad;
+                            a.o_pr = (long long)to.W * to.Cpad; a.o_pc = to.Cpad;
+                        } else {
+                            a.o_bs = (long long)to.H * to.W * to.Cpad; a.o_rs = (long long)to.W * to.Cpad;
+                        }
+                    } else {
+                        const int per = o.out_kind == OUT_CONF ? 3 * C : 12;     // channels per pixel
+                        const int per_prior = o.out_kind == OUT_CONF ? C : 4;
+                        float *base = o.out_kind == OUT_ARM_LOC ? io->arm_loc : (o.out_kind == OUT_ODM_LOC ? io->odm_loc : io->conf);
+                        a.out = base; a.out_f32 = 1;
+                        a.o_base = (long long)scale_off[o.scale] * per_prior;
+                        a.o_bs = (long long)P * per_prior; a.o_rs = (long long)a.Wo * per; a.o_cs = per;
+                    }
+                    rc = launch_conv(a, s);
+                    break;
+                }
+                case OP_POOL: {
+                    const Tensor &ti = tensors[o.in];
+                    rc = launch_maxpool2(tptr(ws, o.in, B), tptr(ws, o.out, B), B, ti.H, ti.W, ti.Cpad, o.ceil, cfg.dtype, s);
+                    break;
+                }
+                case OP_L2NORM: {
+                    const Tensor &ti = tensors[o.in];
+                    rc = launch_l2norm(tptr(ws, o.in, B), (const float *)(wb + o.w_off), tptr(ws, o.out, B),
+                                       (long long)B * ti.H * ti.W, ti.Cpad, cfg.dtype, s);
+                    break;
+                }
+                case OP_DW: {
+                    const Tensor &ti = tensors[o.in];
+                    rc = launch_dwconv3(tptr(ws, o.in, B), (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
+                                        tptr(ws, o.out, B), B, ti.H, ti.W, ti.Cpad, o.stride, o.relu, cfg.dtype, s);
+                    break;
+                }
+                case OP_REFLOC_IN:
+                    if (!io->ref_loc[o.scale]) return TDRN_E_ARG;
+                    rc = launch_nchw_to_nhwc(io->ref_loc[o.scale], tptr(ws, o.out, B), B, 12, o.hw, 12, TDRN_F32, s);
+                    break;
+                case OP_OFFSET: {
+                    const float *loc;
+                    long long bs, ps;
+                    if (o.in >= 0) { loc = (const float *)tptr(ws, o.in, B); bs = (long long)o.hw * 12; ps = 12; }
+                    else { loc = io->arm_loc + (size_t)scale_off[o.scale] * 4; bs = (long long)P * 4; ps = 12; }
+                    rc = launch_offset_conv(loc, bs, ps, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
+                                            (float *)tptr(ws, o.out, B), B, o.hw, 12, o.off_n, s);
+                    break;
+                }
+                case OP_DEFORM: {
+                    const Tensor &ti = tensors[o.in];
+                    const Tensor &tf = tensors[o.off_t];
+                    DeformArgs a;
+                    a.in = tptr(ws, o.in, B); a.zero_page = wb; a.n_branches = o.n_branches;
+                    const float *off = (const float *)tptr(ws, o.off_t, B);
+                    a.br[0] = DeformBranch{off + o.off_c0[0], tf.C, wb + o.w_off, 3, 3, 1, 1, 1, o.G};
+                    if (o.n_branches == 2) a.br[1] = DeformBranch{off + o.off_c0[1], tf.C, wb + o.w2_off, 5, 5, 2, 1, 1, o.G};
+                    a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = ti.H; a.Wo = ti.W; a.Cout = o.Cout; a.Npad = o.Npad;
+                    float *locbase = o.out_kind == OUT_ARM_LOC ? io->arm_loc : io->odm_loc;
+                    a.out0 = locbase + (size_t)scale_off[o.scale] * 4; a.o0_bs = (long long)P * 4; a.o0_ps = 12;
+                    a.out1 = io->conf + (size_t)scale_off[o.scale] * C; a.o1_bs = (long long)P * C; a.o1_ps = 3 * C;
+                    a.split = 12; a.dtype = cfg.dtype;
+                    rc = launch_deform(a, s);
+                    break;
+                }
+                case OP_SOFTMAX:
+                    rc = launch_softmax_rows(io->conf, io->conf, (long long)B * P, C, s);
+                    break;
+                case OP_OFF_OUT: {
+                    const Tensor &tf = tensors[o.in];
+                    rc = launch_nhwc_to_nchw_f32((const float *)tptr(ws, o.in, B), (long long)tf.H * tf.W * tf.C, tf.C,
+                                                 io->offsets[o.scale], B, o.Cout, tf.H * tf.W, s);
+                    break;
+                }
+                case OP_LOC_OUT:
+                    rc = launch_nhwc_to_nchw_f32(io->arm_loc + (size_t)scale_off[o.scale] * 4, (long long)P * 4, 12,
+                                                 io->loc_maps[o.scale], B, 12, fm[o.scale] * fm[o.scale], s);
+                    break;
+            }
+            if (rc != TDRN_OK) return rc;
+            if (profile) {
+                TDRN_HIP_TRY(hipEventRecord(ev[evi + 1], s));
+                ev_stat.push_back(o.stat);
+                evi += 2;
+            }
+        }
+        return TDRN_OK;
+    }
+
+    int collect_stats(tdrn_kernel_stat *out, int max_entries)
+    {
+        for (int i = 0; i < ST_COUNT; ++i) {
+            memset(&stats[i], 0, sizeof(stats[i]));
+            strncpy(stats[i].name, kStatNames[i], sizeof(stats[i].name) - 1);
+        }
+        for (const Op &o : ops) {
+            stats[o.stat].launches += 1;
+            stats[o.stat].flops += o.flops * last_batch;
+            stats[o.stat].bytes += o.bytes * last_batch;
+        }
+        for (size_t i = 0; i < ev_stat.size(); ++i) {
+            float ms = 0.f;
+            TDRN_HIP_TRY(hipEventSynchronize(ev[2 * i + 1]));
+            TDRN_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            stats[ev_stat[i]].ms += ms;
+        }
+        int n = 0;
+        for (int i = 0; i < ST_COUNT && n < max_entries; ++i)
+            if (stats[i].launches) out[n++] = stats[i];
+        return n;
+    }
+};
+
+// ---- C ABI (tdrn_hip.h section iii) ------------------------------------------------------------
+extern "C" {
+
+int tdrn_net_create(const tdrn_net_config *cfg, tdrn_net **out)
+{
+    if (!cfg || !out) return TDRN_E_ARG;
+    tdrn_net *n = new tdrn_net();
+    n->cfg = *cfg;
+    const int rc = n->build();
+    if (rc != TDRN_OK) {
+        delete n;
+        return rc;
+    }
+    *out = n;
+    return TDRN_OK;
+}
+
+void tdrn_net_destroy(tdrn_net *net)
+{
+    if (!net) return;
+    for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
+    delete net;
+}
+
+int tdrn_net_param_count(const tdrn_net *net) { return net ? (int)net->params.size() : TDRN_E_ARG; }
+
+int tdrn_net_param_info(const tdrn_net *net, int index, const char **name, int64_t shape[4], int *ndim)
+{
+    if (!net || index < 0 || index >= (int)net->params.size()) return TDRN_E_ARG;
+    const ParamSpec &p = net->params[index];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape)
+        for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return TDRN_OK;
+}
+
+int tdrn_net_set_param(tdrn_net *net, const char *name, const float *data_host, int64_t numel)
+{
+    if (!net || !name || !data_host) return TDRN_E_ARG;
+    auto it = net->param_index.find(name);
+    if (it == net->param_index.end()) return TDRN_E_PARAM;
+    int64_t want = 1;
+    for (int64_t d : net->params[it->second].shape) want *= d;
+    if (want != numel) return TDRN_E_PARAM;
+    net->staged[name].assign(data_host, data_host + numel);
+    net->weights_ready = false;
+    return TDRN_OK;
+}
+
+size_t tdrn_net_weight_bytes(const tdrn_net *net) { return net ? net->blob_bytes : 0; }
+size_t tdrn_net_workspace_bytes(const tdrn_net *net, int batch) { return net && batch > 0 ? net->ws_per_sample * (size_t)batch : 0; }
+int tdrn_net_num_priors(const tdrn_net *net) { return net ? net->P : TDRN_E_ARG; }
+
+int tdrn_net_pack_weights(tdrn_net *net, void *weights_dev, size_t weights_bytes, void *stream)
+{
+    if (!net || !weights_dev) return TDRN_E_ARG;
+    if (weights_bytes < net->blob_bytes) return TDRN_E_WORKSPACE;
+    for (const ParamSpec &p : net->params)
+        if (!net->staged.count(p.name)) return TDRN_E_PARAM;
+    std::vector<char> host;
+    TDRN_TRY(net->pack(host));
+    hipStream_t s = (hipStream_t)stream;
+    TDRN_HIP_TRY(hipMemcpyAsync(weights_dev, host.data(), host.size(), hipMemcpyHostToDevice, s));
+    TDRN_HIP_TRY(hipStreamSynchronize(s));
+    net->weights_ready = true;
+    net->staged.clear();   // the fp32 staging copy is no longer needed
+    return TDRN_OK;
+}
+
+int tdrn_net_adopt_weights(tdrn_net *net)
+{
+    if (!net) return TDRN_E_ARG;
+    net->weights_ready = true;
+    return TDRN_OK;
+}
+
+int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *workspace, size_t workspace_bytes, const tdrn_net_io *io,
+                     void *stream)
+{
+    if (!net) return TDRN_E_ARG;
+    return net->forward(weights_dev, workspace, workspace_bytes, io, (hipStream_t)stream);
+}
+
+int tdrn_net_profile(tdrn_net *net, int enable)
+{
+    if (!net) return TDRN_E_ARG;
+    net->profile = enable != 0;
+    return TDRN_OK;
+}
+
+int tdrn_net_kernel_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries)
+{
+    if (!net || !out || max_entries <= 0) return TDRN_E_ARG;
+    return net->collect_stats(out, max_entries);
+}
+
+}  // extern "C"

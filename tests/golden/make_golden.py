@@ -1,0 +1,128 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on CPU (build container only).
+
+    python tests/golden/make_golden.py            # writes the fixtures next to this file
+
+The reference tree (/root/reference) is imported through tests/golden/ref_shim.py; nothing of
+it is copied.  Fixtures hold data only: seeds/inputs (or the recipe to regenerate them from
+tdrn_amd.utils.synth) and the reference's outputs.  The deformable op has no runnable reference
+(CUDA + THC only), so inside the reference model `model.networks.conv_offset2d` is patched to
+the oracle's restatement -- every other op in those forwards is the reference's
+own code.  The Cython cpu_nms is un-buildable (Cython 0.25 output vs Python 3.10): the
+reference's own pure-numpy twin utils/nms/py_cpu_nms.py pins the oracle's NMS instead.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shim  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tdrn_amd.utils import synth  # noqa: E402
+
+SUB = 4  # keep every SUB-th prior of the full-net outputs (fixture size)
+
+
+def main():
+    import torch
+    ref = ref_shim.install(cpu_nms=lambda dets, thresh: orc.cpu_nms(dets, thresh))
+    torch.set_num_threads(8)
+    out = {}
+
+    # ---- PriorBox (layers/functions/prior_box.py) -------------------------------------------
+    for name in ("VOC_320", "VOC_512_RefineDet"):
+        pb = ref["PriorBox"](ref["mb_cfg"][name]).forward().numpy()
+        np.savez_compressed(os.path.join(HERE, "priorbox_%s.npz" % name), priors=pb)
+        print("priorbox", name, pb.shape)
+
+    # ---- decode / center_size / L2Norm (layers/box_utils.py, layers/modules/l2norm.py) -------
+    rng = np.random.Generator(np.random.PCG64(11))
+    priors = ref["PriorBox"](ref["mb_cfg"]["VOC_320"]).forward()
+    loc = torch.from_numpy((0.5 * rng.standard_normal((6375, 4))).astype(np.float32))
+    dec = ref["decode"](loc, priors, [0.1, 0.2])
+    cs = ref["center_size"](dec)
+    l2 = ref["L2Norm"](24, 10)
+    l2.weight.data = torch.from_numpy(rng.uniform(5, 15, 24).astype(np.float32))
+    xl = torch.from_numpy(rng.standard_normal((2, 24, 5, 7)).astype(np.float32))
+    with torch.no_grad():
+        yl = l2(xl)
+    np.savez_compressed(os.path.join(HERE, "box_utils.npz"), loc=loc.numpy(), decoded=dec.numpy(),
+                        center_size=cs.numpy(), l2_x=xl.numpy(), l2_w=l2.weight.data.numpy(),
+                        l2_y=yl.numpy())
+
+    # ---- NMS: the reference's numpy twin on tie-free inputs (utils/nms/py_cpu_nms.py) ---------
+    import importlib
+    py_cpu_nms = importlib.import_module("utils.nms.py_cpu_nms").py_cpu_nms
+    cases = {}
+    for ci, (n, spread) in enumerate([(1, 50), (2, 5), (64, 40), (65, 40), (300, 120), (1000, 200),
+                                      (3000, 300)]):
+        xy = rng.uniform(0, spread, (n, 2)).astype(np.float32)
+        wh = rng.uniform(4, 60, (n, 2)).astype(np.float32)
+        sc = rng.permutation(n).astype(np.float32) / np.float32(n) * 0.98 + 0.01  # tie-free
+        dets = np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32)
+        keep = np.asarray(py_cpu_nms(dets, 0.45), np.int32)
+        cases["dets%d" % ci] = dets
+        cases["keep%d" % ci] = keep
+    np.savez_compressed(os.path.join(HERE, "nms_cases.npz"), **cases)
+
+    # ---- Detect (layers/functions/detection.py) on the D6/D8/D9 regimes of SURVEY 8(d) --------
+    for tag, bias, B in (("D8", 8.0, 2), ("D6", 6.0, 1), ("D9", 9.0, 2)):
+        loc_d, arm_d, conf_d = synth.synth_detect_inputs(B, 6375, 21, bias, seed=1)
+        det = ref["Detect"](21, 0, 200, 0.01, 0.45)
+        scale = torch.tensor([500.0, 375.0, 500.0, 375.0])
+        o = det.forward(torch.from_numpy(loc_d), torch.from_numpy(conf_d), priors,
+                        arm_loc_data=torch.from_numpy(arm_d), scale=scale).numpy()
+        o_noarm = det.forward(torch.from_numpy(loc_d), torch.from_numpy(conf_d), priors,
+                              arm_loc_data=None, scale=torch.tensor([320.0] * 4)).numpy()
+        np.savez_compressed(os.path.join(HERE, "detect_%s.npz" % tag), bias=bias, batch=B,
+                            out=o, out_noarm=o_noarm)
+        print("detect", tag, int((o[..., 0] > 0).sum()), int((o_noarm[..., 0] > 0).sum()))
+
+    # ---- full nets with synthetic weights ------------------------------------------------------
+    import model.networks as N
+
+    def patched(input, offset, weight, stride=1, padding=0, dilation=1, deform_groups=1):
+        o = orc.deform_conv_forward(input.detach().numpy(), offset.detach().numpy(),
+                                    weight.detach().numpy(), stride, padding, dilation,
+                                    deform_groups)
+        return torch.from_numpy(o)
+    N.conv_offset2d = patched
+
+    def run(modname, tag, size, build_args, x_seed=0, w_seed=0):
+        mod = importlib.import_module("model." + modname)
+        net = mod.build_net("test", size, 21, *build_args)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = synth.synth_state_dict(shapes, w_seed)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        x = torch.from_numpy(synth.synth_frames(1, size, x_seed))
+        with torch.no_grad():
+            res = net(x)
+        return net, shapes, res
+
+    for tag, size, mh in (("drn_vggbn_320_mh", 320, True), ("drn_vggbn_320", 320, False)):
+        net, shapes, (arm_loc, offs, odm_loc, conf) = run("dualrefinedet_vggbn", tag, size,
+                                                          (1024, 1, True, mh))
+        P = arm_loc.shape[1]
+        pri = ref["PriorBox"](ref["mb_cfg"]["VOC_%d" % size]).forward()
+        det = ref["Detect"](21, 0, 200, 0.01, 0.45).forward(
+            odm_loc, conf, pri, arm_loc_data=arm_loc, scale=torch.tensor([500., 375., 500., 375.]))
+        np.savez_compressed(
+            os.path.join(HERE, tag + ".npz"), sub=SUB, size=size, multihead=mh,
+            keys=np.asarray(list(shapes.keys())),
+            arm_loc=arm_loc.numpy()[:, ::SUB], odm_loc=odm_loc.numpy()[:, ::SUB],
+            conf=conf.numpy().reshape(1, P, 21)[:, ::SUB],
+            off0=offs[0].numpy()[:, :, ::5, ::5], off3=offs[3].numpy(),
+            stats=np.asarray([arm_loc.abs().mean(), odm_loc.abs().mean(), conf.max(),
+                              arm_loc.double().sum(), odm_loc.double().sum()], np.float64),
+            detect=det.numpy())
+        print(tag, "arm|odm mean abs", float(arm_loc.abs().mean()), float(odm_loc.abs().mean()),
+              "conf max", float(conf.max()), "dets", int((det[..., 0] > 0).sum()))
+
+
+if __name__ == "__main__":
+    main()

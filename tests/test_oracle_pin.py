@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/) against the reference's own outputs (tests/golden/*.npz, made by
+tests/golden/make_golden.py from the reference's Python) and against analytic known-answer tests
+for the deformable op, whose reference implementation is CUDA-only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import net_ref
+from oracle import oracle as orc
+from tdrn_amd.utils import synth
+
+VOC_320 = dict(feature_maps=[40, 20, 10, 5], min_dim=320, steps=[8, 16, 32, 64],
+               min_sizes=[32, 64, 128, 256], max_sizes=[], aspect_ratios=[[2], [2], [2], [2]],
+               variance=[0.1, 0.2], clip=True, flip=True, name="VOC_320")
+VOC_512 = dict(VOC_320, feature_maps=[64, 32, 16, 8], min_dim=512, name="VOC_512_RefineDet")
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("cfg,name", [(VOC_320, "VOC_320"), (VOC_512, "VOC_512_RefineDet")])
+def test_priorbox_bit_exact(golden_dir, cfg, name):
+    ref = _g(golden_dir, "priorbox_%s.npz" % name)["priors"]
+    got = orc.prior_box(cfg)
+    assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # closed-form first rows
+    np.testing.assert_allclose(orc.prior_box(VOC_320)[:4], [[.0125, .0125, .1, .1],
+                               [.0125, .0125, .14142136, .07071068],
+                               [.0125, .0125, .07071068, .14142136], [.0375, .0125, .1, .1]], rtol=1e-6)
+
+
+def test_decode_center_size_l2norm(golden_dir):
+    g = _g(golden_dir, "box_utils.npz")
+    pri = orc.prior_box(VOC_320)
+    dec = orc.decode(g["loc"], pri)
+    np.testing.assert_allclose(dec, g["decoded"], rtol=2e-6, atol=1e-7)   # expf vs SLEEF: 1 ulp
+    # everything except the exp is exact: feed the reference's decoded boxes through center_size
+    assert np.array_equal(orc.center_size(g["decoded"]), g["center_size"])
+    np.testing.assert_allclose(orc.l2norm(g["l2_x"], g["l2_w"]), g["l2_y"], rtol=1e-6, atol=1e-7)
+
+
+def test_nms_matches_reference_numpy_twin(golden_dir):
+    g = _g(golden_dir, "nms_cases.npz")
+    n_cases = len([k for k in g.files if k.startswith("dets")])
+    assert n_cases >= 7
+    for i in range(n_cases):
+        dets, keep = g["dets%d" % i], g["keep%d" % i]
+        assert len(np.unique(dets[:, 4])) == len(dets), "fixture must be tie-free"
+        got = np.asarray(orc.cpu_nms(dets, 0.45), np.int32)
+        assert np.array_equal(got, keep), "case %d" % i
+
+
+def test_nms_threshold_equality_rule():
+    # two boxes with IoU exactly 0.5 (+1 convention): 10x10 and 10x10 shifted so inter=... ;
+    # a = [0,0,9,9] (area 100), b = [0,0,9,4]+... choose inter/union = 50/100
+    a = [0, 0, 9, 9, 0.9]
+    b = [0, 0, 9, 4, 0.8]                  # area 50, inter 50, union 100 -> ovr = 0.5 exactly
+    dets = np.asarray([a, b], np.float32)
+    assert orc.cpu_nms(dets, 0.5) == [0]                   # cpu_nms.pyx:66  ovr >= thresh
+    assert orc.cpu_nms(dets, 0.5, strict_gt=True) == [0, 1]  # nms_kernel.cu:71 ovr > thresh
+    assert orc.cpu_nms(dets, 0.5000001) == [0, 1]
+    assert orc.cpu_nms(np.zeros((0, 5), np.float32), 0.5) == []
+
+
+@pytest.mark.parametrize("tag", ["D8", "D9", "D6"])
+def test_detect_matches_reference(golden_dir, tag):
+    g = _g(golden_dir, "detect_%s.npz" % tag)
+    B = int(g["batch"])
+    loc, arm, conf = synth.synth_detect_inputs(B, 6375, 21, float(g["bias"]), seed=1)
+    pri = orc.prior_box(VOC_320)
+    out = orc.detect(loc, conf, pri, arm, (500, 375, 500, 375))
+    ref = g["out"]
+    assert np.array_equal(out[..., 0], ref[..., 0])        # scores/slot occupancy: exact
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+    out2 = orc.detect(loc, conf, pri, None, (320,) * 4)
+    assert np.array_equal(out2[..., 0], g["out_noarm"][..., 0])
+    np.testing.assert_allclose(out2, g["out_noarm"], rtol=3e-6, atol=1e-6)
+
+
+# ---- deformable conv known-answer tests (utils/deformconv/deform_conv_cuda_kernel.cu:15-51,156-208)
+def _rand(shape, seed):
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("k,pad", [(3, 1), (5, 2), (1, 0)])
+def test_deform_zero_offset_is_plain_conv(k, pad):
+    x, w = _rand((2, 6, 9, 7), 1), _rand((5, 6, k, k), 2)
+    off = np.zeros((2, 2 * k * k, 9, 7), np.float32)
+    got = orc.deform_conv_forward(x, off, w, 1, pad, 1, 1)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, 1, pad).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_deform_integer_offset_is_shifted_conv():
+    # constant offset (+1 row, +2 cols): sample x[h+1, w+2]; rows/cols past the far edge clamp...
+    x, w = _rand((1, 4, 8, 8), 3), _rand((3, 4, 3, 3), 4)
+    off = np.zeros((1, 18, 8, 8), np.float32)
+    off[:, 0::2] = 1.0
+    off[:, 1::2] = 2.0
+    got = orc.deform_conv_forward(x, off, w, 1, 1, 1, 1)
+    # build the shifted image with the kernel's border rule: coordinates >= H (or W) -> 0,
+    # negative -> 0, integer coords inside -> exact value.
+    xs = np.zeros((1, 4, 8 + 2 + 4, 8 + 2 + 4), np.float32)      # generous zero canvas
+    xs[:, :, 2:10, 2:10] = x
+    # out(h,w) tap (i,j) reads x[h-1+i+1, w-1+j+2] = canvas[h+i+2, w+j+3]
+    shifted = xs[:, :, 2:, 3:]
+    ref = F.conv2d(torch.from_numpy(np.ascontiguousarray(shifted)), torch.from_numpy(w)).numpy()
+    np.testing.assert_allclose(got, ref[:, :, :8, :8], rtol=1e-4, atol=1e-5)
+
+
+def test_deform_border_rules_single_pixel():
+    H = W = 4
+    x = np.arange(16, dtype=np.float32).reshape(1, 1, H, W) + 1.0
+    w = np.ones((1, 1, 1, 1), np.float32)
+
+    def sample(h, wq, dh, dw):
+        off = np.zeros((1, 2, H, W), np.float32)
+        off[0, 0, h, wq], off[0, 1, h, wq] = dh, dw
+        return float(orc.deform_conv_forward(x, off, w, 1, 0, 1, 1)[0, 0, h, wq])
+    assert sample(1, 1, 0.5, 0.0) == pytest.approx((x[0, 0, 1, 1] + x[0, 0, 2, 1]) / 2)
+    assert sample(0, 0, -0.25, 0.0) == 0.0                     # h_im in (-1,0): hard zero (:195)
+    assert sample(0, 0, 0.0, -1e-3) == 0.0
+    assert sample(3, 2, 0.75, 0.0) == x[0, 0, 3, 2]             # h_im in (H-1,H): clamps to row H-1
+    assert sample(2, 3, 0.0, 0.5) == x[0, 0, 2, 3]              # w_im in (W-1,W): clamps to col W-1
+    assert sample(3, 3, 1.0, 0.0) == 0.0                        # h_im == H: rejected
+    assert sample(3, 3, 0.999, 0.999) == x[0, 0, 3, 3]
+    v = sample(2, 2, 0.5, 0.5)                                 # interior bilinear
+    assert v == pytest.approx(x[0, 0, 2:4, 2:4].mean())
+
+
+def test_deform_group_indexing():
+    # G=2: channels [0,2) use offset group 0, [2,4) group 1 (.cu:172)
+    x, w = _rand((1, 4, 6, 6), 5), _rand((2, 4, 3, 3), 6)
+    off = np.zeros((1, 2 * 18, 6, 6), np.float32)
+    off[:, 18:] = _rand((1, 18, 6, 6), 7) * 0.7
+    got = orc.deform_conv_forward(x, off, w, 1, 1, 1, 2)
+    x0, x1 = x.copy(), x.copy()
+    x0[:, 2:] = 0
+    x1[:, :2] = 0
+    a = orc.deform_conv_forward(x0, off[:, :18], w, 1, 1, 1, 1)
+    b = orc.deform_conv_forward(x1, off[:, 18:], w, 1, 1, 1, 1)
+    np.testing.assert_allclose(got, a + b, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        orc.deform_conv_forward(x, off[:, :18], w, 1, 1, 1, 2)  # offset channels != G*2*kh*kw
+
+
+@pytest.mark.parametrize("tag,mh", [("drn_vggbn_320_mh", True), ("drn_vggbn_320", False)])
+def test_full_net_restatement_matches_reference(golden_dir, tag, mh):
+    """oracle/net_ref.py vs the reference's RefineSSD.forward (deformable op patched to the oracle)."""
+    g = _g(golden_dir, tag + ".npz")
+    keys = [str(k) for k in g["keys"]]
+    shapes = _drn_vggbn_shapes(mh)
+    assert list(shapes.keys()) == keys                   # same state_dict layout as the reference
+    sd = synth.synth_state_dict(shapes, 0)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    arm, offs, odm, conf = net_ref.drn_vggbn_forward(sd, synth.synth_frames(1, 320, 0), 21, True, mh)
+    sub = int(g["sub"])
+    P = arm.shape[1]
+    np.testing.assert_allclose(arm.numpy()[:, ::sub], g["arm_loc"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(odm.numpy()[:, ::sub], g["odm_loc"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(conf.numpy().reshape(1, P, 21)[:, ::sub], g["conf"], rtol=1e-4,
+                               atol=2e-5)
+    np.testing.assert_allclose(offs[3].numpy(), g["off3"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(offs[0].numpy()[:, :, ::5, ::5], g["off0"], rtol=1e-4, atol=2e-5)
+    assert float(g["stats"][3]) == pytest.approx(float(arm.double().sum()), rel=1e-4, abs=1e-2)
+
+
+def _drn_vggbn_shapes(multihead, c7=1024, nc=21):
+    """State-dict layout of model/dualrefinedet_vggbn.py, incl. num_batches_tracked."""
+    from tdrn_amd.model.layout import drn_vggbn_shapes
+    return drn_vggbn_shapes(multihead=multihead, c7_channel=c7, num_classes=nc, bn=True)
