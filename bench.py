@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the dual-refinement detector hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path -- build_net(...)'s forward + Detect -- over one batch of
+synthetic frames already resident in HBM (BASELINE.json configs[1]: dualrefinedet_vggbn 320x320,
+bf16, batch 32 per GPU, multihead, synthetic VOC-shaped frames, synthetic weights).  N>1: every rank
+runs its own batch (frames shard, weights arrive by one RCCL broadcast, no per-frame collective):
+weak scaling, value = all ranks' frames / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (conv_igemm_mfma): algorithmic FLOPs of its launches in one
+                 step / their summed hipEvent durations, against the dense bf16 MFMA peak
+  cpu_baseline : the CPU oracle (torch-CPU convs + C deformable conv + C Detect) on a bounded sample
+                 of the same workload on this host's cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md, dense
+GFLOP_PER_FRAME = {320: 77.466, 512: 198.314}                   # BASELINE.md section 2 (multihead)
+
+
+def cpu_baseline(size, frames=2):
+    """Oracle forward + Detect on `frames` frames; returns the cpu_baseline object."""
+    import torch
+    from oracle import net_ref
+    from oracle import oracle as orc
+    from tdrn_amd.model.dualrefinedet_vggbn import build_net
+    from tdrn_amd.utils import synth
+    net = build_net("test", size, 21, 1024, 1, True, True)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(feature_maps=[size // 8, size // 16, size // 32, size // 64], min_dim=size, steps=[8, 16, 32, 64],
+               min_sizes=[32, 64, 128, 256], max_sizes=[], aspect_ratios=[[2]] * 4, variance=[0.1, 0.2], clip=True,
+               flip=True, name="bench")
+    pri = orc.prior_box(cfg)
+    x = synth.synth_frames(frames, size, seed=0)
+    net_ref.drn_vggbn_forward(sdt, x[:1], 21, True, True)          # warm-up (thread pools, page-in)
+    t0 = time.perf_counter()
+    for i in range(frames):
+        arm, _, odm, conf = net_ref.drn_vggbn_forward(sdt, x[i:i + 1], 21, True, True)
+        orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), (500, 375, 500, 375))
+    dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same workload, batch 1, fp32 (oracle/: torch-CPU convs + C deformable "
+                      "conv + C Detect), %.1f s" % (frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=11)           # evaluate.py:463 drops the first 11 frames
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=320)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    from tdrn_amd import dist as tdist
+    from tdrn_amd.data import mb_cfg
+    from tdrn_amd.layers import Detect, PriorBox
+    from tdrn_amd.model.dualrefinedet_vggbn import build_net
+    from tdrn_amd.utils import synth
+
+    rank, local_rank, world = tdist.init()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    net = build_net("test", args.size, 21, 1024, 1, True, True)
+    net.set_compute_dtype(args.dtype)
+    if rank == 0:
+        sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    if world > 1:
+        eng = net.adopt_broadcast_weights(src=0, device=dev)     # the one collective: weights over xGMI
+    else:
+        eng = net.engine(dev)
+    B = args.batch
+    x = torch.from_numpy(synth.synth_frames(B, args.size, seed=100 + rank)).to(dev)
+    pri = PriorBox(mb_cfg["VOC_320" if args.size == 320 else "VOC_512_RefineDet"]).forward().to(dev)
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    scale = [500.0, 375.0, 500.0, 375.0]
+
+    def step():
+        r = eng.forward(x)
+        if args.no_detect:
+            return r["conf"]
+        return det.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
+
+    for _ in range(args.warmup):
+        step()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    tdist.barrier()
+    dt = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    fps = world * B * args.steps / dt
+
+    # ---- forward-only split and per-kernel roofline (separate, event-instrumented passes) ---------
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        eng.forward(x)
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
+    eng.set_profile(True)
+    eng.forward(x)
+    eng.forward(x)
+    torch.cuda.synchronize()
+    stats = eng.kernel_stats()
+    eng.set_profile(False)
+    conv = [s for s in stats if s["name"] == "conv_igemm_mfma"][0]
+    peak = PEAK_TFLOPS[args.dtype]
+    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_mfma", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": conv["launches"], "gflop_per_step": round(conv["flops"] / 1e9, 2),
+                "ms_per_step": round(conv["ms"], 4)}
+    kernels = {s["name"]: {"ms": round(s["ms"], 4), "launches": s["launches"],
+                           "gflop": round(s["flops"] / 1e9, 3), "gbyte": round(s["bytes"] / 1e9, 4)} for s in stats}
+
+    if rank == 0:
+        line = {
+            "metric": "frames/sec/GPU @%dx%d dualrefinedet_vggbn; box Linf vs CPU ref" % (args.size, args.size),
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "dualrefinedet_vggbn %dx%d multihead, %s, batch %d per GPU, forward%s, synthetic "
+                                   "VOC-shaped frames + synthetic weights" %
+                                   (args.size, args.size, args.dtype, B, "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
+                       "global_batch": world * B, "parallelism": "frame-sharded x%d, no per-frame collective" % world},
+            "fps_per_gpu": round(fps / world, 2),
+            "forward_only_ms_per_step": round(fwd_ms, 4),
+            "forward_tflops": round(GFLOP_PER_FRAME.get(args.size, 0) * B / fwd_ms, 2),
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_frames)
+        print(json.dumps(line))
+    tdist.barrier()
+
+
+if __name__ == "__main__":
+    main()

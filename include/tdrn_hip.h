@@ -214,6 +214,17 @@ typedef struct {
 TDRN_API int tdrn_net_profile(tdrn_net *net, int enable);
 TDRN_API int tdrn_net_kernel_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries);
 
+/* Test / debug access to the plan's internal activation tensors (NHWC, net dtype) after a
+ * forward on the same workspace: tdrn_net_tensor_info names tensor `index` after the parameter
+ * that produced it (e.g. "backbone.3", "L2Norm_4_3", "pool:backbone.3"); tdrn_net_read_tensor
+ * converts it to fp32 NCHW (B,C,H,W) into out_dev.  Used by tests/ to compare every stage with
+ * the oracle; not part of the hot path. */
+TDRN_API int tdrn_net_tensor_count(const tdrn_net *net);
+TDRN_API int tdrn_net_tensor_info(const tdrn_net *net, int index, const char **label, int *C, int *H,
+                                  int *W);
+TDRN_API int tdrn_net_read_tensor(const tdrn_net *net, const void *workspace, int batch, int index,
+                                  float *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,7 @@ def deform(x, offset, weight, padding, groups=1):
     return torch.from_numpy(out)
 
 
-def vgg_trunk(sd, x, bn=True):
+def vgg_trunk(sd, x, bn=True, taps=None):
     """model/networks.py:136-163 walked as model/dualrefinedet_vggbn.py:130-150 does.
     Returns (conv4_3 relu, conv5_3 relu, fc7 relu)."""
     idx = 0
@@ -63,6 +63,8 @@ def vgg_trunk(sd, x, bn=True):
             if bn:
                 x = _bn(sd, "backbone.%d" % (idx + 1), x)
             x = F.relu(x)
+            if taps is not None:
+                taps["backbone.%d" % idx] = x
             idx += 3 if bn else 2
             n_conv += 1
             if n_conv in (10, 13):          # conv4_3, conv5_3
@@ -73,16 +75,21 @@ def vgg_trunk(sd, x, bn=True):
     if bn:
         x = _bn(sd, "backbone.%d" % (idx + 1), x)
     x = F.relu(x)
+    if taps is not None:
+        taps["backbone.%d" % idx] = x
     idx += 3 if bn else 2
     x = _conv(sd, "backbone.%d" % idx, x)
     if bn:
         x = _bn(sd, "backbone.%d" % (idx + 1), x)
     x = F.relu(x)
+    if taps is not None:
+        taps["backbone.%d" % idx] = x
     feats.append(x)
     return feats
 
 
-def _drn_head(sd, arm_sources, x_last, num_classes, multihead, phase, def_groups=1):
+def _drn_head(sd, arm_sources, x_last, num_classes, multihead, phase, def_groups=1, taps=None):
+    tp = taps if taps is not None else {}
     """The part shared by dualrefinedet_vggbn.py:154-206 and dualrefinedet_mobilenet.py:151-199."""
     arm_loc_list, off1, off2 = [], [], []
     for s, a in enumerate(arm_sources):
@@ -91,24 +98,32 @@ def _drn_head(sd, arm_sources, x_last, num_classes, multihead, phase, def_groups
         off1.append(_conv(sd, "offset.%d" % s, loc_a))
         if multihead:
             off2.append(_conv(sd, "offset2.%d" % s, loc_a))
+        tp["offset.%d" % s] = torch.cat([off1[-1]] + ([off2[-1]] if multihead else []), 1)
     arm_loc = torch.cat([o.view(o.size(0), -1) for o in arm_loc_list], 1)
     # last_layer_trans: conv, ReLU, conv, conv (no ReLU after 2nd/3rd)
     x = _conv(sd, "last_layer_trans.0", x_last, padding=1)
     x = F.relu(x)
+    tp["last_layer_trans.0"] = x
     x = _conv(sd, "last_layer_trans.2", x, padding=1)
+    tp["last_layer_trans.2"] = x
     x = _conv(sd, "last_layer_trans.3", x, padding=1)
+    tp["last_layer_trans.3"] = x
     odm_sources = [x]
     trans = []
     for s in range(3):
         t = _conv(sd, "trans_layers.%d.0" % s, arm_sources[s], padding=1)
         t = F.relu(t)
+        tp["trans_layers.%d.0" % s] = t
         trans.append(_conv(sd, "trans_layers.%d.2" % s, t, padding=1))
+        tp["trans_layers.%d.2" % s] = trans[-1]
     trans.reverse()
     for i, t in enumerate(trans):
         w = _t(sd, "up_layers.%d.weight" % i)
         b = _t(sd, "up_layers.%d.bias" % i) if ("up_layers.%d.bias" % i) in sd else None
-        u = F.conv_transpose2d(x, w, b, stride=2)
-        x = F.relu(_conv(sd, "latent_layers.%d" % i, F.relu(u + t), padding=1))
+        u = F.relu(F.conv_transpose2d(x, w, b, stride=2) + t)
+        tp["up_layers.%d" % i] = u
+        x = F.relu(_conv(sd, "latent_layers.%d" % i, u, padding=1))
+        tp["latent_layers.%d" % i] = x
         odm_sources.append(x)
     odm_sources.reverse()
     loc_list, conf_list = [], []
@@ -131,22 +146,28 @@ def _drn_head(sd, arm_sources, x_last, num_classes, multihead, phase, def_groups
 
 
 def drn_vggbn_forward(sd, x, num_classes=21, bn=True, multihead=False, phase="test",
-                      def_groups=1):
+                      def_groups=1, taps=None):
     """model/dualrefinedet_vggbn.py:119-206."""
     x = torch.as_tensor(x)
     with torch.no_grad():
-        c43, c53, fc7 = vgg_trunk(sd, x, bn)
+        tp = taps if taps is not None else {}
+        c43, c53, fc7 = vgg_trunk(sd, x, bn, taps)
         srcs = [_l2norm(sd, "L2Norm_4_3", c43), _l2norm(sd, "L2Norm_5_3", c53), fc7]
+        tp["L2Norm_4_3"], tp["L2Norm_5_3"] = srcs[0], srcs[1]
         e = _conv(sd, "extras.0", fc7)
         if bn:
             e = F.relu(_bn(sd, "extras.1", e))
+            tp["extras.0"] = e
             e = _conv(sd, "extras.3", e, stride=2, padding=1)
             e = F.relu(_bn(sd, "extras.4", e))
+            tp["extras.3"] = e
         else:
             e = F.relu(e)
+            tp["extras.0"] = e
             e = F.relu(_conv(sd, "extras.2", e, stride=2, padding=1))
+            tp["extras.2"] = e
         srcs.append(e)
-        return _drn_head(sd, srcs, e, num_classes, multihead, phase, def_groups)
+        return _drn_head(sd, srcs, e, num_classes, multihead, phase, def_groups, taps)
 
 
 def _conv_dw(sd, name, x, stride):

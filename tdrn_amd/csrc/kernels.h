@@ -66,6 +66,8 @@ int launch_repack_oihw(const float *w, void *out, int Cout, int Npad, int Cin, i
                        hipStream_t s);
 int launch_nhwc_to_nchw_f32(const float *in, long long in_bs, long long in_ps, float *out, int B,
                             int C, int HW, hipStream_t s);   // fp32 "NHWC view" -> fp32 NCHW
+// NHWC (channel stride Cpad, dtype DT or fp32) -> fp32 NCHW
+int launch_nhwc_any_to_nchw_f32(const void *in, int dtype, int Cpad, float *out, int B, int C, int HW, hipStream_t s);
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

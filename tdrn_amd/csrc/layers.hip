@@ -389,6 +389,31 @@ int launch_nhwc_to_nchw_f32(const float *in, long long in_bs, long long in_ps, f
     return hip_status(hipGetLastError());
 }
 
+template <typename DT>
+__global__ __launch_bounds__(256) void nhwc_any_to_nchw_kernel(const char *__restrict__ in, int Cpad, float *__restrict__ out,
+                                                               int B, int C, int HW)
+{
+    constexpr int ES = elem_traits<DT>::bytes;
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const long long bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        out[i] = to_f32<DT>(*(const DT *)(in + (((size_t)b * HW + pix) * Cpad + c) * ES));
+    }
+}
+
+int launch_nhwc_any_to_nchw_f32(const void *in, int dtype, int Cpad, float *out, int B, int C, int HW, hipStream_t s)
+{
+    const long long total = (long long)B * C * HW;
+    if (total <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+#define L(DT) hipLaunchKernelGGL((nhwc_any_to_nchw_kernel<DT>), grid, dim3(256), 0, s, (const char *)in, Cpad, out, B, C, HW)
+    if (dtype == TDRN_F32) L(float); else if (dtype == TDRN_BF16) L(bf16_t); else L(f16_t);
+#undef L
+    return hip_status(hipGetLastError());
+}
+
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s)
 {
     return hip_status(hipMemsetAsync(p, 0, bytes, s));

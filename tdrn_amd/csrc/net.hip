@@ -38,7 +38,7 @@ enum OpKind { OP_FIRST, OP_CONV, OP_POOL, OP_L2NORM, OP_DW, OP_OFFSET, OP_DEFORM
               OP_REFLOC_IN };
 enum OutKind { OUT_TENSOR = 0, OUT_ARM_LOC = 1, OUT_ODM_LOC = 2, OUT_CONF = 3 };
 
-struct Tensor { int C, Cpad, H, W; bool f32; size_t off; /* bytes per sample from workspace start */ };
+struct Tensor { int C, Cpad, H, W; bool f32; size_t off; /* bytes per sample from workspace start */ std::string label; };
 struct ParamSpec { std::string name; std::vector<int64_t> shape; };
 
 struct Op {
@@ -101,6 +101,7 @@ struct tdrn_net {
     {
         P_(bn + ".weight", {C}); P_(bn + ".bias", {C}); P_(bn + ".running_mean", {C}); P_(bn + ".running_var", {C});
     }
+    void label(int t, const std::string &l) { if (t >= 0) tensors[t].label = l; }
     size_t blob(size_t bytes)
     {
         const size_t o = blob_bytes;
@@ -123,6 +124,7 @@ struct tdrn_net {
         o.b_off = blob((size_t)tensors[o.out].Cpad * 4);
         o.flops = 2.0 * So * So * Cout * 27;
         o.bytes = 3.0 * S * S * 4 + (double)So * So * tensors[o.out].Cpad * es;
+        label(o.out, w);
         ops.push_back(o);
         return o.out;
     }
@@ -155,6 +157,7 @@ struct tdrn_net {
         o.flops = 2.0 * Ho * Wo * Cout * (double)k * k * ti.C;
         o.bytes = (double)ti.H * ti.W * ti.Cpad * es + (double)Ho * Wo * o.Cout * (out_kind == OUT_TENSOR ? es : 4) +
                   (res >= 0 ? (double)Ho * Wo * o.Cout * es : 0.0);
+        label(o.out, w);
         ops.push_back(o);
         return o.out;
     }
@@ -175,6 +178,7 @@ struct tdrn_net {
         o.b_off = blob((size_t)o.Npad * 4);
         o.flops = 2.0 * 4 * ti.H * ti.W * (double)Cout * ti.C;
         o.bytes = (double)ti.H * ti.W * ti.Cpad * es + 2.0 * 4 * ti.H * ti.W * o.Cout * es;
+        label(o.out, w);
         ops.push_back(o);
         return o.out;
     }
@@ -186,6 +190,7 @@ struct tdrn_net {
         const int Ho = ceil_mode ? (ti.H + 1) / 2 : ti.H / 2, Wo = ceil_mode ? (ti.W + 1) / 2 : ti.W / 2;
         o.out = T(ti.C, Ho, Wo);
         o.bytes = ((double)ti.H * ti.W + (double)Ho * Wo) * ti.Cpad * es;
+        label(o.out, "pool:" + ti.label);
         ops.push_back(o);
         return o.out;
     }
@@ -198,6 +203,7 @@ struct tdrn_net {
         o.out = T(ti.C, ti.H, ti.W);
         o.w_off = blob((size_t)ti.Cpad * 4);
         o.bytes = 2.0 * ti.H * ti.W * ti.Cpad * es;
+        label(o.out, name);
         ops.push_back(o);
         return o.out;
     }
@@ -214,6 +220,7 @@ struct tdrn_net {
         o.b_off = blob((size_t)ti.Cpad * 4);
         o.flops = 2.0 * Ho * Wo * ti.C * 9;
         o.bytes = ((double)ti.H * ti.W + (double)Ho * Wo) * ti.Cpad * es;
+        label(o.out, w);
         ops.push_back(o);
         return o.out;
     }
@@ -244,6 +251,7 @@ struct tdrn_net {
         o.b_off = blob((size_t)o.off_n * 4);
         o.flops = 2.0 * H * W * o.off_n * 12;
         o.bytes = (double)H * W * (12 + o.off_n) * 4;
+        label(o.out, w1);
         ops.push_back(o);
         return o.out;
     }
@@ -880,6 +888,27 @@ int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *workspace, si
 {
     if (!net) return TDRN_E_ARG;
     return net->forward(weights_dev, workspace, workspace_bytes, io, (hipStream_t)stream);
+}
+
+int tdrn_net_tensor_count(const tdrn_net *net) { return net ? (int)net->tensors.size() : TDRN_E_ARG; }
+
+int tdrn_net_tensor_info(const tdrn_net *net, int index, const char **label, int *C, int *H, int *W)
+{
+    if (!net || index < 0 || index >= (int)net->tensors.size()) return TDRN_E_ARG;
+    const Tensor &t = net->tensors[index];
+    if (label) *label = t.label.c_str();
+    if (C) *C = t.C;
+    if (H) *H = t.H;
+    if (W) *W = t.W;
+    return TDRN_OK;
+}
+
+int tdrn_net_read_tensor(const tdrn_net *net, const void *workspace, int batch, int index, float *out_dev, void *stream)
+{
+    if (!net || !workspace || !out_dev || batch <= 0 || index < 0 || index >= (int)net->tensors.size()) return TDRN_E_ARG;
+    const Tensor &t = net->tensors[index];
+    return launch_nhwc_any_to_nchw_f32((const char *)workspace + t.off * (size_t)batch, t.f32 ? TDRN_F32 : net->cfg.dtype,
+                                       t.Cpad, out_dev, batch, t.C, t.H * t.W, (hipStream_t)stream);
 }
 
 int tdrn_net_profile(tdrn_net *net, int enable)

@@ -1,0 +1,167 @@
+"""NetEngine -- thin host-side owner of one tdrn_net handle (include/tdrn_hip.h section iii).
+
+PyTorch is plumbing here: it allocates the weight blob, the activation workspace and the output
+tensors on the GPU and supplies the HIP stream; every kernel is launched by libtdrn_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NetConfig, NetIO, KernelStat, check, ptr
+
+
+class NetEngine(object):
+    def __init__(self, model, size, num_classes=21, c7_channel=1024, def_groups=1, bn=True,
+                 multihead=False, deform=False, test_phase=True, dtype="fp32"):
+        self.lib = _lib.lib()
+        self.dtype_name = dtype
+        cfg = NetConfig(model=model, size=size, num_classes=num_classes, c7_channel=c7_channel,
+                        def_groups=def_groups, bn=int(bool(bn)), multihead=int(bool(multihead)),
+                        deform=int(bool(deform)), test_phase=int(bool(test_phase)),
+                        dtype=_lib.DTYPES[dtype])
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(self.lib.tdrn_net_create(C.byref(cfg), C.byref(h)), "tdrn_net_create")
+        self.handle = h
+        self.num_classes = num_classes
+        self.num_priors = self.lib.tdrn_net_num_priors(h)
+        self.fm = [size // 8, size // 16, size // 32, size // 64]
+        self.weights = None          # device blob (torch.uint8)
+        self._ws = None
+        self.device = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tdrn_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- parameters -----------------------------------------------------------------------
+    def param_specs(self):
+        out = []
+        for i in range(self.lib.tdrn_net_param_count(self.handle)):
+            name, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            check(self.lib.tdrn_net_param_info(self.handle, i, C.byref(name), C.byref(shape), C.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value))))
+        return out
+
+    def load(self, state_dict, device):
+        """state_dict: {name: tensor/ndarray} in the reference's key layout.  Entries the plan does
+        not use (num_batches_tracked) are ignored; a missing or mis-shaped one raises."""
+        for name, shape in self.param_specs():
+            if name not in state_dict:
+                raise KeyError("state_dict is missing %r" % name)
+            v = state_dict[name]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(v.shape) != shape:
+                raise ValueError("size mismatch for %s: expected %r, got %r" % (name, shape, tuple(v.shape)))
+            check(self.lib.tdrn_net_set_param(self.handle, name.encode(), v.ctypes.data_as(C.c_void_p), v.size), name)
+        self._alloc_weights(device)
+        check(self.lib.tdrn_net_pack_weights(self.handle, ptr(self.weights), self.weights.numel(),
+                                             _lib.current_stream(self.device)), "pack_weights")
+
+    def _alloc_weights(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise NotImplementedError("tdrn_amd runs on the GPU only (no CPU path)")
+        n = self.lib.tdrn_net_weight_bytes(self.handle)
+        self.weights = torch.zeros(n, dtype=torch.uint8, device=self.device)
+
+    def broadcast_weights(self, src=0):
+        """One RCCL broadcast of the packed blob over xGMI; every other rank adopts it (no
+        per-frame collective follows).  Call after load() on rank `src`, instead of load() elsewhere."""
+        import torch.distributed as dist
+        if self.weights is None:
+            self._alloc_weights(torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(self.weights, src=src)
+        check(self.lib.tdrn_net_adopt_weights(self.handle))
+
+    # ---- forward --------------------------------------------------------------------------
+    def workspace(self, batch):
+        need = self.lib.tdrn_net_workspace_bytes(self.handle, batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None):
+        _lib.require_cuda(x, "input")
+        if self.weights is None:
+            raise RuntimeError("weights were never packed (load() / broadcast_weights())")
+        if x.dim() != 4 or x.size(1) != 3 or x.size(2) != self.cfg.size or x.size(3) != self.cfg.size:
+            raise ValueError("expected input (B,3,%d,%d), got %r" % (self.cfg.size, self.cfg.size, tuple(x.shape)))
+        x = x.contiguous().float()
+        B, P, Cn = x.size(0), self.num_priors, self.num_classes
+        dev = x.device
+        ws = self.workspace(B)
+        ssd = self.cfg.model in (_lib.SSD4SCALE_MOBILE, _lib.SSD4SCALE_VGG)
+        o = out or {}
+        arm_loc = o.get("arm_loc")
+        if arm_loc is None:
+            arm_loc = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+        odm_loc = None
+        if not ssd:
+            odm_loc = o.get("odm_loc")
+            if odm_loc is None:
+                odm_loc = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+        conf = o.get("conf")
+        if conf is None:
+            conf = torch.empty((B * P, Cn), dtype=torch.float32, device=dev)
+        io = NetIO()
+        io.x = x.data_ptr()
+        io.batch = B
+        io.arm_loc = arm_loc.data_ptr()
+        io.odm_loc = odm_loc.data_ptr() if odm_loc is not None else None
+        io.conf = conf.data_ptr()
+        offsets, loc_maps, keep = None, None, [x]
+        if want_offsets:
+            g18 = (8 if self.cfg.deform else self.cfg.def_groups) * 18
+            offsets = [torch.empty((B, g18, f, f), dtype=torch.float32, device=dev) for f in self.fm]
+            for i, t in enumerate(offsets):
+                io.offsets[i] = t.data_ptr()
+        if ref_loc is not None:
+            for i, t in enumerate(ref_loc):
+                t = t.contiguous().float()
+                keep.append(t)
+                io.ref_loc[i] = t.data_ptr()
+        if want_loc_maps:
+            loc_maps = [torch.empty((B, 12, f, f), dtype=torch.float32, device=dev) for f in self.fm]
+            for i, t in enumerate(loc_maps):
+                io.loc_maps[i] = t.data_ptr()
+        check(self.lib.tdrn_net_forward(self.handle, ptr(self.weights), ptr(ws), ws.numel(), C.byref(io),
+                                        _lib.current_stream(dev)), "tdrn_net_forward")
+        res = {"arm_loc": arm_loc, "odm_loc": odm_loc, "conf": conf, "offsets": offsets, "loc_maps": loc_maps}
+        return res
+
+    # ---- debug / test access to internal activations ------------------------------------------
+    def tensor_infos(self):
+        out = []
+        for i in range(self.lib.tdrn_net_tensor_count(self.handle)):
+            lab, c, h, w = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
+            check(self.lib.tdrn_net_tensor_info(self.handle, i, C.byref(lab), C.byref(c), C.byref(h), C.byref(w)))
+            out.append((lab.value.decode(), c.value, h.value, w.value))
+        return out
+
+    def read_tensor(self, index, batch):
+        lab, c, h, w = self.tensor_infos()[index]
+        out = torch.empty((batch, c, h, w), dtype=torch.float32, device=self.device)
+        check(self.lib.tdrn_net_read_tensor(self.handle, ptr(self._ws), batch, index, ptr(out),
+                                            _lib.current_stream(self.device)))
+        return out
+
+    # ---- accounting for bench.py -------------------------------------------------------------
+    def set_profile(self, on):
+        check(self.lib.tdrn_net_profile(self.handle, int(bool(on))))
+
+    def kernel_stats(self):
+        arr = (KernelStat * 16)()
+        n = self.lib.tdrn_net_kernel_stats(self.handle, arr, 16)
+        if n < 0:
+            check(n)
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, flops=arr[i].flops,
+                     bytes=arr[i].bytes, ms=arr[i].ms) for i in range(n)]

@@ -1,0 +1,2 @@
+from .functions import *   # noqa: F401,F403
+from .modules import *     # noqa: F401,F403

