@@ -88,19 +88,23 @@ def test_drn_vggbn_matches_reference_golden(golden_dir, tag, mh):
     np.testing.assert_allclose(det, mine, rtol=3e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("dtype,tol_loc,tol_conf", [("bf16", 0.25, 0.08), ("fp16", 0.03, 0.01)])
+@pytest.mark.parametrize("dtype,tol_loc,tol_conf", [("bf16", 0.12, 0.05), ("fp16", 0.015, 0.006)])
 def test_drn_vggbn_16bit_drift_is_bounded(dtype, tol_loc, tol_conf):
+    """bf16/fp16 drift is reported separately from the 1e-3 fp32 claim.  The
+    deformable sampling rule is discontinuous at the top/left border (a coordinate of -0.001 gives 0,
+    +0.001 the full value: deform_conv_cuda_kernel.cu:195), so a handful of ODM outputs can move by
+    O(1) when 16-bit offsets cross it; the bound is therefore on the mean and the 99.9th percentile."""
     net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
     net.set_compute_dtype(dtype)
     x = synth.synth_frames(1, 320, seed=5)
     ref_arm, _, ref_odm, ref_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, True)
     arm, _, odm, conf = net(torch.from_numpy(x).to(DEV))
-    e_arm = float((arm.cpu() - ref_arm).abs().max())
-    e_odm = float((odm.cpu() - ref_odm).abs().max())
-    e_conf = float((conf.cpu() - ref_conf).abs().max())
-    print("%s drift: arm %.4g odm %.4g conf %.4g" % (dtype, e_arm, e_odm, e_conf))
-    assert e_arm < tol_loc and e_odm < tol_loc * 2 and e_conf < tol_conf
-    assert float((arm.cpu() - ref_arm).abs().mean()) < tol_loc / 20
+    rep = {}
+    for name, got, ref, tol in (("arm", arm, ref_arm, tol_loc), ("odm", odm, ref_odm, 2 * tol_loc), ("conf", conf, ref_conf, tol_conf)):
+        e = (got.cpu() - ref).abs().flatten()
+        rep[name] = (float(e.mean()), float(torch.quantile(e, 0.999)), float(e.max()))
+        assert rep[name][0] < tol / 8 and rep[name][1] < tol, (name, rep[name])
+    print("%s drift (mean, p99.9, max): %r" % (dtype, rep))
 
 
 def test_batch32_rows_equal_single_frame_runs():
