@@ -78,7 +78,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = t >> 3;
     const int lc16 = ((t & 7) ^ ((lrow >> 1) & 7)) << 4;   // swizzled source chunk (bytes)
-    const int mt = blockIdx.x / p.n_tiles, nt = blockIdx.x - mt * p.n_tiles;
+    // XCD-aware remap (bijective): workgroups are dealt round-robin over the 8 XCDs, each with its
+    // own L2; give every XCD a contiguous run of tiles so that the cout-tile siblings of a pixel
+    // tile and neighbouring pixel tiles (shared 3x3 halo) hit the same L2.
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+    const int mt = wg / p.n_tiles, nt = wg - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.z;
     const char *wbase = p.w + (size_t)z * p.Npad * p.Ktot * ES;

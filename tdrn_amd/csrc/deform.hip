@@ -28,6 +28,14 @@ struct DeformParams {
     float *out0, *out1;
     long long o0_bs, o0_ps, o1_bs, o1_ps;
 };
+// several independent problems (the four pyramid levels) in ONE launch: their K loops are
+// latency-bound per workgroup, so running them side by side costs the time of the longest.
+constexpr int kMaxDeformProblems = 4;
+struct DeformMulti {
+    DeformParams p[kMaxDeformProblems];
+    int block_start[kMaxDeformProblems + 1];
+    int n;
+};
 
 template <typename DT> struct MmaD;
 template <> struct MmaD<bf16_t> {
@@ -49,8 +57,13 @@ template <> struct MmaD<float> {
 
 // 128 pixels x (NTL*32) couts per workgroup; wave w owns pixels [32w, 32w+32) and all cout tiles.
 template <typename DT, int NTL>
-__global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
+__global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
 {
+    int prob = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxDeformProblems; ++i)
+        if (i < mp.n && (int)blockIdx.x >= mp.block_start[i]) prob = i;
+    const DeformParams &p = mp.p[prob];
     constexpr int BM = 128, BN = NTL * 32, NT = 256, RPP = 32, PA = BM / RPP;
     constexpr int ES = elem_traits<DT>::bytes;
     constexpr int P16 = elem_traits<DT>::per16;
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = t >> 3, pc = t & 7;
     const int lc16 = (pc ^ ((lrow >> 1) & 7)) << 4;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = ((int)blockIdx.x - mp.block_start[prob]) * BM;
     const int HoWo = p.Ho * p.Wo;
 
     int ho_[PA], wo_[PA], ibase[PA];
@@ -133,10 +146,13 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
         }
     };
 
-    auto produce = [&](int buf) {
+    // one K-step of operands: weights by LDS-DMA; the four bilinear corners of each of this
+    // thread's pixel rows go to registers first (issue) and are blended into LDS one MFMA phase
+    // later (finish), so their L2 latency hides under the matrix work of the previous K-step.
+    u32x4 raw[PA][4];
+    auto issue = [&](int buf) {
         char *sb = smem + buf * STAGE;
         const DeformBranchP &B = p.br[br];
-        // weights: LDS-DMA, swizzle on the source address
         const int Ktot = B.kh * B.kw * p.Cin;
 #pragma unroll
         for (int i = 0; i < NTL; ++i) {
@@ -144,19 +160,29 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(sb + (i * RPP + wave * 8) * 128), 16, 0, 0);
         }
-        // sampled activations: 4 corner rows -> fp32 blend -> DT -> LDS (physical chunk pc)
         const int coffs = cc * CK * ES + lc16;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            u32x4 raw[4];
+        for (int i = 0; i < PA; ++i)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) raw[k] = *(const u32x4 *)(p.in + (size_t)coff[i][k] * ES + coffs);
+            for (int k = 0; k < 4; ++k) raw[i][k] = *(const u32x4 *)(p.in + (size_t)coff[i][k] * ES + coffs);
+    };
+    float fw[PA][4];      // weights that belong to the registers in flight
+    auto latch_weights = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fw[i][k] = cw[i][k];
+    };
+    auto finish = [&](int buf) {
+        char *sb = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
             float v[4][P16], o[P16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) unpack16<DT>(raw[k], v[k]);
+            for (int k = 0; k < 4; ++k) unpack16<DT>(raw[i][k], v[k]);
 #pragma unroll
             for (int j = 0; j < P16; ++j)
-                o[j] = fmaf(cw[i][3], v[3][j], fmaf(cw[i][2], v[2][j], fmaf(cw[i][1], v[1][j], cw[i][0] * v[0][j])));
+                o[j] = fmaf(fw[i][3], v[3][j], fmaf(fw[i][2], v[2][j], fmaf(fw[i][1], v[1][j], fw[i][0] * v[0][j])));
             *(u32x4 *)(sb + BN * 128 + (i * RPP + lrow) * 128 + pc * 16) = pack16<DT>(o);
         }
     };
@@ -198,15 +224,21 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
     };
 
     tap_params();
-    produce(0);
+    issue(0);
+    latch_weights();
+    finish(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     bool more = true;
     while (more) {
         more = advance();
-        if (more) produce(cur ^ 1);
+        if (more) {
+            issue(cur ^ 1);
+            latch_weights();
+        }
         compute(cur);
+        if (more) finish(cur ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
@@ -236,27 +268,26 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformParams p)
 
 int deform_n_pad(int cout) { return (int)align_up((size_t)cout, 32); }
 
-template <typename DT> static int launch_deform_dt(const DeformParams &p, hipStream_t s)
+template <typename DT> static int launch_deform_dt(const DeformMulti &mp, int ntl, hipStream_t s)
 {
-    dim3 grid((unsigned)cdiv(p.M, 128));
-    switch (p.Npad / 32) {
-        case 1: hipLaunchKernelGGL((deform_gemm_kernel<DT, 1>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((deform_gemm_kernel<DT, 2>), grid, dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((deform_gemm_kernel<DT, 3>), grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((deform_gemm_kernel<DT, 4>), grid, dim3(256), 0, s, p); break;
+    dim3 grid((unsigned)mp.block_start[mp.n]);
+    switch (ntl) {
+        case 1: hipLaunchKernelGGL((deform_gemm_kernel<DT, 1>), grid, dim3(256), 0, s, mp); break;
+        case 2: hipLaunchKernelGGL((deform_gemm_kernel<DT, 2>), grid, dim3(256), 0, s, mp); break;
+        case 3: hipLaunchKernelGGL((deform_gemm_kernel<DT, 3>), grid, dim3(256), 0, s, mp); break;
+        case 4: hipLaunchKernelGGL((deform_gemm_kernel<DT, 4>), grid, dim3(256), 0, s, mp); break;
         default: return TDRN_E_UNSUPPORTED;
     }
     return hip_status(hipGetLastError());
 }
 
-int launch_deform(const DeformArgs &a, hipStream_t s)
+static int fill_params(const DeformArgs &a, DeformParams &p)
 {
     if (!a.in || !a.out0 || a.n_branches < 1 || a.n_branches > 2) return TDRN_E_ARG;
     const int es = dtype_bytes(a.dtype), ck = 128 / es;
     if (a.Npad % 32 || a.Npad > 128 || a.Cout > a.Npad || a.Cout < 1) return TDRN_E_UNSUPPORTED;
     if (a.split < a.Cout && !a.out1) return TDRN_E_ARG;
     if ((long long)a.B * a.H * a.W * a.Cin >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
-    DeformParams p;
     p.in = (const char *)a.in;
     p.zero = (const char *)a.zero_page;
     p.n_branches = a.n_branches;
@@ -271,13 +302,35 @@ int launch_deform(const DeformArgs &a, hipStream_t s)
     p.split = a.split > a.Cout ? a.Cout : a.split;
     p.out0 = a.out0; p.out1 = a.out1;
     p.o0_bs = a.o0_bs; p.o0_ps = a.o0_ps; p.o1_bs = a.o1_bs; p.o1_ps = a.o1_ps;
-    if (p.M <= 0) return TDRN_OK;
-    switch (a.dtype) {
-        case TDRN_F32: return launch_deform_dt<float>(p, s);
-        case TDRN_BF16: return launch_deform_dt<bf16_t>(p, s);
-        case TDRN_F16: return launch_deform_dt<f16_t>(p, s);
+    return TDRN_OK;
+}
+
+// all problems must share dtype and Npad (they do: the pyramid levels of one model)
+int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s)
+{
+    if (!args || n < 1 || n > kMaxDeformProblems) return TDRN_E_ARG;
+    DeformMulti mp;
+    mp.n = 0;
+    mp.block_start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (args[i].dtype != args[0].dtype || args[i].Npad != args[0].Npad) return TDRN_E_UNSUPPORTED;
+        DeformParams p;
+        TDRN_TRY(fill_params(args[i], p));
+        if (p.M <= 0) continue;
+        mp.p[mp.n] = p;
+        mp.block_start[mp.n + 1] = mp.block_start[mp.n] + cdiv(p.M, 128);
+        ++mp.n;
+    }
+    if (mp.n == 0) return TDRN_OK;
+    for (int i = mp.n; i < kMaxDeformProblems; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
+    switch (args[0].dtype) {
+        case TDRN_F32: return launch_deform_dt<float>(mp, args[0].Npad / 32, s);
+        case TDRN_BF16: return launch_deform_dt<bf16_t>(mp, args[0].Npad / 32, s);
+        case TDRN_F16: return launch_deform_dt<f16_t>(mp, args[0].Npad / 32, s);
     }
     return TDRN_E_ARG;
 }
+
+int launch_deform(const DeformArgs &a, hipStream_t s) { return launch_deform_multi(&a, 1, s); }
 
 }  // namespace tdrn

@@ -11,11 +11,11 @@
 // candidates are ordered by (score desc, prior index asc).  Given identical fp32 boxes/scores
 // the keep lists equal cpu_nms's on tie-free scores.
 //
-// Pipeline (3 launches + 2 memsets, no host sync):
+// Pipeline (2 launches + 1 memset, no host sync):
 //   detect_decode_kernel   : two-stage decode, normalised boxes + boxes*scale
-//   detect_gather_kernel   : score > conf_thresh -> per-(image,class) candidate key lists
-//   detect_nms_kernel      : per segment: bitonic sort in LDS, wave-64 greedy NMS against an
-//                            LDS-resident keep list, early exit at top_k, pack output rows
+//   detect_nms_kernel      : per (image,class): score > conf_thresh compaction into LDS keys,
+//                            bitonic sort, wave-64 greedy NMS against an LDS-resident keep list,
+//                            early exit at top_k, pack output rows
 #include "kernels.h"
 
 namespace tdrn {
@@ -95,25 +95,6 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restr
     *(f32x4 *)(boxes + (size_t)i * 4) = f32x4{b[0], b[1], b[2], b[3]};
     *(f32x4 *)(sboxes + (size_t)i * 4) =
         f32x4{__fmul_rn(b[0], scale[0]), __fmul_rn(b[1], scale[1]), __fmul_rn(b[2], scale[2]), __fmul_rn(b[3], scale[3])};
-}
-
-// detection.py:53: c_mask = conf_scores[cl].gt(conf_thresh).  key = score bits : ~prior index
-__global__ __launch_bounds__(256) void detect_gather_kernel(const float *__restrict__ conf, int B, int P, int C,
-                                                            float conf_thresh, unsigned long long *__restrict__ keys,
-                                                            int *__restrict__ counts)
-{
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)B * P) return;
-    const int b = (int)(i / P), p = (int)(i - (long long)b * P);
-    const float *row = conf + (size_t)i * C;
-    for (int cl = 1; cl < C; ++cl) {
-        const float sc = row[cl];
-        if (sc > conf_thresh) {
-            const int seg = b * C + cl;
-            const int pos = atomicAdd(&counts[seg], 1);
-            keys[(size_t)seg * P + pos] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
-        }
-    }
 }
 
 // ---- shared device pieces -------------------------------------------------------------------
@@ -199,25 +180,49 @@ __device__ __forceinline__ int wave_greedy_nms(int n, int cap, float bound, int 
 }
 
 // ---- Detect: one workgroup per (image, class) segment -------------------------------------
+// detection.py:52-63.  The workgroup scans its class column of conf (score > conf_thresh, :53),
+// compacts the candidates into LDS as 64-bit keys (score bits : ~prior index), sorts them, and
+// wave 0 runs the greedy NMS against an LDS-resident keep list.
 __global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
-                                                         const unsigned long long *__restrict__ keys,
-                                                         const int *__restrict__ counts, int P, int C, int top_k,
-                                                         float bound, int kcap, float *__restrict__ out,
-                                                         int *__restrict__ counts_out)
+                                                         const float *__restrict__ conf, int P, int C, int top_k,
+                                                         float conf_thresh, float bound, int kcap,
+                                                         float *__restrict__ out, int *__restrict__ counts_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
     unsigned long long *sk = dsm;
     Box *kept = (Box *)(dsm + kcap);
+    int *cnt = (int *)(kept + top_k);
     const int seg = blockIdx.x;          // b*C + cl
     const int cl = seg % C, b = seg / C;
-    const int n = cl == 0 ? 0 : counts[seg];
+    if (cl == 0) {
+        if (counts_out && threadIdx.x == 0) counts_out[seg] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const float *col = conf + (size_t)b * P * C + cl;
+    for (int p0 = 0; p0 < P; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        const float sc = p < P ? col[(size_t)p * C] : 0.f;
+        const bool pass = p < P && sc > conf_thresh;
+        const unsigned long long m = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (pass)
+            sk[base + __popcll(m & ((1ull << lane) - 1ull))] =
+                ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+    }
+    __syncthreads();
+    const int n = *cnt;
     if (n == 0) {
         if (counts_out && threadIdx.x == 0) counts_out[seg] = 0;
         return;
     }
     int N = 64;
     while (N < n) N <<= 1;
-    for (int i = threadIdx.x; i < N; i += 256) sk[i] = i < n ? keys[(size_t)seg * P + i] : 0ull;
+    for (int i = n + threadIdx.x; i < N; i += 256) sk[i] = 0ull;
     __syncthreads();
     bitonic_sort_desc(sk, N, threadIdx.x, 256);
     if (threadIdx.x >= 64) return;
@@ -247,12 +252,8 @@ static int next_pow2(int v) { int n = 64; while (n < v) n <<= 1; return n; }
 
 size_t detect_workspace_bytes(int B, int P, int C, int top_k)
 {
-    (void)top_k;
-    size_t s = 0;
-    s += align_up((size_t)B * P * 4 * sizeof(float), 256) * 2;                    // boxes, sboxes
-    s += align_up((size_t)B * C * sizeof(int), 256);                              // counts
-    s += align_up((size_t)B * C * P * sizeof(unsigned long long), 256);           // keys
-    return s;
+    (void)top_k; (void)C;
+    return align_up((size_t)B * P * 4 * sizeof(float), 256) * 2;                  // boxes, boxes*scale
 }
 
 int launch_detect(const float *loc, const float *conf, const float *priors, const float *arm_loc, const float *scale4,
@@ -264,30 +265,25 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
     if (B <= 0 || P <= 0 || C < 2 || top_k <= 0) return TDRN_E_ARG;
     if (ws_bytes < detect_workspace_bytes(B, P, C, top_k)) return TDRN_E_WORKSPACE;
     const int kcap = next_pow2(P);
-    const size_t lds = (size_t)kcap * 8 + (size_t)top_k * sizeof(Box);
+    const size_t lds = (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 16;
     if (lds > 160 * 1024) return TDRN_E_UNSUPPORTED;
     char *w = (char *)ws;
     float *boxes = (float *)w;  w += align_up((size_t)B * P * 4 * sizeof(float), 256);
-    float *sboxes = (float *)w; w += align_up((size_t)B * P * 4 * sizeof(float), 256);
-    int *counts = (int *)w;     w += align_up((size_t)B * C * sizeof(int), 256);
-    unsigned long long *keys = (unsigned long long *)w;
+    float *sboxes = (float *)w;
     // (double)ovr >= thresh  <=>  ovr >= bound, bound = smallest fp32 whose double value >= thresh
     float bound = (float)nms_thresh;
     if ((double)bound < nms_thresh) bound = nextafterf(bound, INFINITY);
-    TDRN_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)B * C * sizeof(int), s));
     TDRN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * C * top_k * 5 * sizeof(float), s));
     const long long bp = (long long)B * P;
     hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((bp + 255) / 256)), dim3(256), 0, s, loc, arm_loc, priors, B, P,
                        f32x4{scale4[0], scale4[1], scale4[2], scale4[3]}, boxes, sboxes);
-    hipLaunchKernelGGL(detect_gather_kernel, dim3((unsigned)((bp + 255) / 256)), dim3(256), 0, s, conf, B, P, C, conf_thresh,
-                       keys, counts);
     static bool attr_set = false;
     if (!attr_set) {
         TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds, s, boxes, sboxes, keys, counts, P, C, top_k,
-                       bound, kcap, out, counts_out);
+    hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds, s, boxes, sboxes, conf, P, C, top_k,
+                       conf_thresh, bound, kcap, out, counts_out);
     return hip_status(hipGetLastError());
 }
 

@@ -97,6 +97,8 @@ struct DeformArgs {
     int dtype = TDRN_BF16;
 };
 int launch_deform(const DeformArgs &a, hipStream_t s);
+// up to 4 independent problems (same dtype / Npad) in one launch
+int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s);
 int deform_n_pad(int cout);
 
 // ---------------------------------------------------------------------------------------------

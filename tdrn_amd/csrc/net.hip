@@ -8,6 +8,7 @@
 //   model/refinedet_vgg.py:27-219            build_refinedet_vgg()
 //   model/ssd4scale_vgg.py                   build_ssd4scale_vgg()
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -53,6 +54,7 @@ struct Op {
     size_t w_off = 0, b_off = 0, w2_off = 0;               // blob offsets
     double flops = 0, bytes = 0;                           // algorithmic, per sample
     int stat = 0;
+    int lane = 0;                                          // HIP stream lane (0 = the caller's stream)
 };
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
@@ -80,6 +82,16 @@ struct tdrn_net {
     std::vector<int> ev_stat;
     tdrn_kernel_stat stats[ST_COUNT];
     int last_batch = 0;
+    // independent branches of the tail (TCB laterals, ARM heads) run on side streams; dependencies
+    // between lanes are hipEvents on the producing tensor.  Created lazily at the first forward.
+    static constexpr int kLanes = 4;
+    int cur_lane = 0;
+    bool use_lanes = true, lanes_ready = false;
+    hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> tensor_ev;
+    std::vector<int> tensor_lane;
+    std::vector<char> tensor_shared;
 
     // ---- plan building --------------------------------------------------------------------
     int T(int C, int H, int W, bool f32 = false)
@@ -101,6 +113,7 @@ struct tdrn_net {
     {
         P_(bn + ".weight", {C}); P_(bn + ".bias", {C}); P_(bn + ".running_mean", {C}); P_(bn + ".running_var", {C});
     }
+    void push(Op &o) { o.lane = cur_lane; ops.push_back(o); }
     void label(int t, const std::string &l) { if (t >= 0) tensors[t].label = l; }
     size_t blob(size_t bytes)
     {
@@ -125,7 +138,7 @@ struct tdrn_net {
         o.flops = 2.0 * So * So * Cout * 27;
         o.bytes = 3.0 * S * S * 4 + (double)So * So * tensors[o.out].Cpad * es;
         label(o.out, w);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -158,7 +171,7 @@ struct tdrn_net {
         o.bytes = (double)ti.H * ti.W * ti.Cpad * es + (double)Ho * Wo * o.Cout * (out_kind == OUT_TENSOR ? es : 4) +
                   (res >= 0 ? (double)Ho * Wo * o.Cout * es : 0.0);
         label(o.out, w);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -179,7 +192,7 @@ struct tdrn_net {
         o.flops = 2.0 * 4 * ti.H * ti.W * (double)Cout * ti.C;
         o.bytes = (double)ti.H * ti.W * ti.Cpad * es + 2.0 * 4 * ti.H * ti.W * o.Cout * es;
         label(o.out, w);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -191,7 +204,7 @@ struct tdrn_net {
         o.out = T(ti.C, Ho, Wo);
         o.bytes = ((double)ti.H * ti.W + (double)Ho * Wo) * ti.Cpad * es;
         label(o.out, "pool:" + ti.label);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -204,7 +217,7 @@ struct tdrn_net {
         o.w_off = blob((size_t)ti.Cpad * 4);
         o.bytes = 2.0 * ti.H * ti.W * ti.Cpad * es;
         label(o.out, name);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -221,7 +234,7 @@ struct tdrn_net {
         o.flops = 2.0 * Ho * Wo * ti.C * 9;
         o.bytes = ((double)ti.H * ti.W + (double)Ho * Wo) * ti.Cpad * es;
         label(o.out, w);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
     // conv_dw block, model/networks.py:736-745
@@ -252,7 +265,7 @@ struct tdrn_net {
         o.flops = 2.0 * H * W * o.off_n * 12;
         o.bytes = (double)H * W * (12 + o.off_n) * 4;
         label(o.out, w1);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -280,22 +293,22 @@ struct tdrn_net {
         o.hw = ti.H * 65536 + ti.W;
         o.flops = 2.0 * ti.H * ti.W * o.Cout * taps * ti.C;
         o.bytes = (double)ti.H * ti.W * (ti.Cpad * es + (o.Cout + 2 * taps * G) * 4);
-        ops.push_back(o);
+        push(o);
     }
 
     void softmax_op()
     {
         Op o; o.kind = OP_SOFTMAX; o.stat = ST_SOFTMAX;
         o.bytes = 2.0 * P * cfg.num_classes * 4;
-        ops.push_back(o);
+        push(o);
     }
-    void offsets_out(int scale, int off_t, int n) { Op o; o.kind = OP_OFF_OUT; o.stat = ST_LAYOUT; o.scale = scale; o.in = off_t; o.Cout = n; ops.push_back(o); }
-    void loc_maps_out(int scale) { Op o; o.kind = OP_LOC_OUT; o.stat = ST_LAYOUT; o.scale = scale; ops.push_back(o); }
+    void offsets_out(int scale, int off_t, int n) { Op o; o.kind = OP_OFF_OUT; o.stat = ST_LAYOUT; o.scale = scale; o.in = off_t; o.Cout = n; push(o); }
+    void loc_maps_out(int scale) { Op o; o.kind = OP_LOC_OUT; o.stat = ST_LAYOUT; o.scale = scale; push(o); }
     int ref_loc_in(int scale, int H, int W)
     {
         Op o; o.kind = OP_REFLOC_IN; o.stat = ST_LAYOUT; o.scale = scale; o.hw = H * W;
         o.out = T(12, H, W, true);
-        ops.push_back(o);
+        push(o);
         return o.out;
     }
 
@@ -344,10 +357,12 @@ struct tdrn_net {
         odm[3] = x;
         int t[3];
         for (int s = 0; s < 3; ++s) {
+            cur_lane = s == 0 ? 1 : 2;      // lateral branches are independent of the top-down chain
             const std::string n = "trans_layers." + std::to_string(s);
             const int a = conv(src[s], n + ".0", bias, "", 256, 3, 1, 1, 1, 1);
             t[s] = conv(a, n + ".2", bias, "", 256, 3, 1, 1, 1, 0);
         }
+        cur_lane = 0;
         for (int i = 0; i < 3; ++i) {
             const int lvl = 2 - i;
             const int u = conv_transpose2(x, "up_layers." + std::to_string(i), bias, 256, t[lvl], 1);
@@ -359,6 +374,7 @@ struct tdrn_net {
     void drn_heads(const int src[4], const int odm[4], bool bias)
     {
         int off_t[4];
+        cur_lane = 3;                       // ARM heads + offset convs: off the critical path
         for (int s = 0; s < 4; ++s) {
             const std::string ss = std::to_string(s);
             conv(src[s], "arm_loc." + ss, bias, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
@@ -366,6 +382,7 @@ struct tdrn_net {
                                    cfg.def_groups * 18, cfg.def_groups * 50, OUT_ARM_LOC);
             offsets_out(s, off_t[s], cfg.def_groups * 18);
         }
+        cur_lane = 0;
         for (int s = 0; s < 4; ++s) {
             const std::string ss = std::to_string(s);
             deform_heads(odm[s], off_t[s], s, cfg.def_groups, "odm_loc." + ss, "odm_conf." + ss,
@@ -469,12 +486,39 @@ struct tdrn_net {
         if (cfg.num_classes < 2 || cfg.num_classes > 21 * 4) return TDRN_E_ARG;
         if (cfg.dtype < 0 || cfg.dtype > 2) return TDRN_E_ARG;
         if (cfg.def_groups < 1) return TDRN_E_ARG;
+        int rc;
         switch (cfg.model) {
-            case TDRN_DRN_VGGBN: return build_drn_vgg();
-            case TDRN_DRN_MOBILENET: return build_drn_mobilenet();
-            case TDRN_SSD4SCALE_MOBILE: return build_ssd4scale(true);
+            case TDRN_DRN_VGGBN: rc = build_drn_vgg(); break;
+            case TDRN_DRN_MOBILENET: rc = build_drn_mobilenet(); break;
+            case TDRN_SSD4SCALE_MOBILE: rc = build_ssd4scale(true); break;
             default: return TDRN_E_UNSUPPORTED;
         }
+        if (rc != TDRN_OK) return rc;
+        const char *e = getenv("TDRN_STREAMS");
+        if (e && atoi(e) <= 1) use_lanes = false;
+        tensor_lane.assign(tensors.size(), 0);
+        tensor_shared.assign(tensors.size(), 0);
+        for (const Op &o : ops)
+            if (o.out >= 0) tensor_lane[o.out] = o.lane;
+        for (const Op &o : ops)
+            for (int t : {o.in, o.res, o.off_t})
+                if (t >= 0 && tensor_lane[t] != o.lane) tensor_shared[t] = 1;
+        return TDRN_OK;
+    }
+
+    int init_lanes()
+    {
+        if (lanes_ready) return TDRN_OK;
+        for (int i = 0; i < kLanes - 1; ++i) {
+            TDRN_HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+            TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
+        TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        tensor_ev.assign(tensors.size(), nullptr);
+        for (size_t t = 0; t < tensors.size(); ++t)
+            if (tensor_shared[t]) TDRN_HIP_TRY(hipEventCreateWithFlags(&tensor_ev[t], hipEventDisableTiming));
+        lanes_ready = true;
+        return TDRN_OK;
     }
 
     // ---- weight packing -----------------------------------------------------------------------
@@ -652,7 +696,7 @@ struct tdrn_net {
     // ---- forward ------------------------------------------------------------------------------
     char *tptr(void *ws, int id, int B) const { return (char *)ws + tensors[id].off * (size_t)B; }
 
-    int forward(const void *blob, void *ws, size_t ws_bytes, const tdrn_net_io *io, hipStream_t s)
+    int forward(const void *blob, void *ws, size_t ws_bytes, const tdrn_net_io *io, hipStream_t s0)
     {
         if (!weights_ready) return TDRN_E_STATE;
         if (!blob || !ws || !io || !io->x || io->batch <= 0) return TDRN_E_ARG;
@@ -671,12 +715,33 @@ struct tdrn_net {
             for (size_t i = old; i < ev.size(); ++i) TDRN_HIP_TRY(hipEventCreate(&ev[i]));
         }
         ev_stat.clear();
-        for (const Op &o : ops) {
+        // profiling runs single-stream so that per-kernel durations are not polluted by overlap
+        const bool lanes = use_lanes && !profile;
+        bool lane_used[kLanes] = {true, false, false, false};
+        if (lanes) {
+            TDRN_TRY(init_lanes());
+            TDRN_HIP_TRY(hipEventRecord(ev_fork, s0));
+        }
+        DeformArgs dargs[4];
+        int n_dargs = 0;
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+            const Op &o = ops[oi];
             bool skip = false;
             if (o.kind == OP_OFF_OUT && !io->offsets[o.scale]) skip = true;
             if (o.kind == OP_LOC_OUT && !io->loc_maps[o.scale]) skip = true;
             if (skip) continue;
-            if (profile) { TDRN_HIP_TRY(hipEventRecord(ev[evi], s)); }
+            const int lane = lanes ? o.lane : 0;
+            hipStream_t s = lane == 0 ? s0 : side[lane - 1];
+            if (lanes) {
+                if (!lane_used[lane]) {
+                    TDRN_HIP_TRY(hipStreamWaitEvent(s, ev_fork, 0));
+                    lane_used[lane] = true;
+                }
+                for (int t : {o.in, o.res, o.off_t})
+                    if (t >= 0 && tensor_lane[t] != lane) TDRN_HIP_TRY(hipStreamWaitEvent(s, tensor_ev[t], 0));
+            }
+            const bool deform_batched = o.kind == OP_DEFORM && oi + 1 < ops.size() && ops[oi + 1].kind == OP_DEFORM && n_dargs < 3;
+            if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) { TDRN_HIP_TRY(hipEventRecord(ev[evi], s)); }
             int rc = TDRN_OK;
             switch (o.kind) {
                 case OP_FIRST:
@@ -755,7 +820,11 @@ struct tdrn_net {
                     a.out0 = locbase + (size_t)scale_off[o.scale] * 4; a.o0_bs = (long long)P * 4; a.o0_ps = 12;
                     a.out1 = io->conf + (size_t)scale_off[o.scale] * C; a.o1_bs = (long long)P * C; a.o1_ps = 3 * C;
                     a.split = 12; a.dtype = cfg.dtype;
-                    rc = launch_deform(a, s);
+                    dargs[n_dargs++] = a;
+                    if (!deform_batched) {      // all pyramid levels in one launch
+                        rc = launch_deform_multi(dargs, n_dargs, s);
+                        n_dargs = 0;
+                    }
                     break;
                 }
                 case OP_SOFTMAX:
@@ -773,12 +842,19 @@ struct tdrn_net {
                     break;
             }
             if (rc != TDRN_OK) return rc;
-            if (profile) {
+            if (lanes && o.out >= 0 && tensor_shared[o.out]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.out], s));
+            if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) {
                 TDRN_HIP_TRY(hipEventRecord(ev[evi + 1], s));
                 ev_stat.push_back(o.stat);
                 evi += 2;
             }
         }
+        if (lanes)
+            for (int l = 1; l < kLanes; ++l)
+                if (lane_used[l]) {
+                    TDRN_HIP_TRY(hipEventRecord(ev_join[l - 1], side[l - 1]));
+                    TDRN_HIP_TRY(hipStreamWaitEvent(s0, ev_join[l - 1], 0));
+                }
         return TDRN_OK;
     }
 
@@ -788,8 +864,10 @@ struct tdrn_net {
             memset(&stats[i], 0, sizeof(stats[i]));
             strncpy(stats[i].name, kStatNames[i], sizeof(stats[i].name) - 1);
         }
+        bool prev_deform = false;
         for (const Op &o : ops) {
-            stats[o.stat].launches += 1;
+            if (!(o.kind == OP_DEFORM && prev_deform)) stats[o.stat].launches += 1;
+            prev_deform = o.kind == OP_DEFORM;
             stats[o.stat].flops += o.flops * last_batch;
             stats[o.stat].bytes += o.bytes * last_batch;
         }
@@ -827,6 +905,12 @@ void tdrn_net_destroy(tdrn_net *net)
 {
     if (!net) return;
     for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : net->tensor_ev) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < tdrn_net::kLanes - 1; ++i) {
+        if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
+        if (net->side[i]) (void)hipStreamDestroy(net->side[i]);
+    }
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     delete net;
 }
 
