@@ -15,6 +15,8 @@
 //     through LDS with 16-byte writes and leaves the chip as whole NHWC rows (16 B per lane).
 //   * fp32 mode uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) on the same 128-byte tiles;
 //     it is the reference-precision path the parity tests pin to 1e-3.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace tdrn {
@@ -60,7 +62,10 @@ __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
 }
 
 // BM = pixel tile, BN = cout tile, waves arranged WGM (pixels) x WGN (couts).
-template <typename DT, int BM, int BN, int WGM, int WGN>
+// STAGES = 2: one K-step prefetched, vmcnt(0) + __syncthreads() per step (small problems, 2 blocks/CU).
+// STAGES = 3: LDS ring with TWO K-steps of LDS-DMA in flight across a raw s_barrier and a counted
+//             s_waitcnt vmcnt(N) -- one workgroup per CU, latency hidden by prefetch depth, not occupancy.
+template <typename DT, int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvParams p)
 {
     constexpr int NT = 64 * WGM * WGN;
@@ -70,8 +75,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     constexpr int PA = BM / RPP, PB = BN / RPP;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int CS = BN * 4 + 16;          // fp32 C-tile row stride (bytes), padded
-    constexpr int LDS = (2 * STAGE > BM * CS) ? 2 * STAGE : BM * CS;
+    constexpr int LDS = (STAGES * STAGE > BM * CS) ? STAGES * STAGE : BM * CS;
     constexpr int WP = BM / WGM / 32, WC = BN / WGN / 32;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(BM % RPP == 0 && BN % RPP == 0 && WP >= 1 && WC >= 1, "tile shape");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
 
@@ -165,17 +171,46 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     };
 
     const int nk = p.kh * p.kw * (p.Cin / CK);
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) {
-            advance();
-            stage(cur ^ 1);
-        }
-        compute(cur);
+    if constexpr (STAGES == 2) {
+        stage(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ks = 0; ks < nk; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < nk) {
+                advance();
+                stage(cur ^ 1);
+            }
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // every stage() issues exactly PA+PB LDS-DMA instructions per lane, so "all but the newest
+        // PA+PB" == "K-step ks has landed".  Read a buffer only after the wait AND the barrier that
+        // follow its loads; refill it only after the barrier that follows its last read.
+        constexpr int LPS = PA + PB;
+        stage(0);
+        if (nk > 1) {
+            advance();
+            stage(1);
+        }
+        int cur = 0, nxt = 2;
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ks + 2 < nk) {
+                advance();
+                stage(nxt);
+            }
+            __builtin_amdgcn_s_setprio(1);
+            compute(cur);
+            __builtin_amdgcn_s_setprio(0);
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        }
         __syncthreads();
     }
 
@@ -254,22 +289,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
 
 int conv_n_pad(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : (int)align_up((size_t)cout, 128)); }
 
-template <typename DT, int BM, int BN, int WGM, int WGN>
+template <typename DT, int BM, int BN, int WGM, int WGN, int STAGES>
 static int launch_cfg(const ConvParams &p, int phases, hipStream_t s)
 {
     const int mt = cdiv(p.M, BM);
     ConvParams q = p;
     q.n_tiles = p.Npad / BN;
     dim3 grid((unsigned)(mt * q.n_tiles), 1, (unsigned)phases);
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), 0, s, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WGM, WGN, STAGES>), grid, dim3(64 * WGM * WGN), 0, s, q);
     return hip_status(hipGetLastError());
 }
 
+static int g_conv_variant = -1;   // TDRN_CONV_VARIANT: 0 = always the 2-stage kernels (A/B switch)
+
 template <typename DT> static int launch_dt(const ConvParams &p, int phases, hipStream_t s)
 {
-    if (p.Npad % 128 == 0) return launch_cfg<DT, 128, 128, 2, 2>(p, phases, s);
-    if (p.Npad % 64 == 0) return launch_cfg<DT, 128, 64, 2, 2>(p, phases, s);
-    return launch_cfg<DT, 128, 32, 4, 1>(p, phases, s);
+    if (g_conv_variant < 0) {
+        const char *e = getenv("TDRN_CONV_VARIANT");
+        g_conv_variant = e ? atoi(e) : 1;
+    }
+    // the deep-pipelined 256x128 kernel runs one workgroup per CU: use it when the grid still has
+    // at least ~2 waves of workgroups over the 256 CUs
+    const long long big_tiles = (long long)cdiv(p.M, 256) * (p.Npad / 128) * phases;
+    if (g_conv_variant >= 1 && p.Npad % 128 == 0 && big_tiles >= 512) return launch_cfg<DT, 256, 128, 4, 2, 3>(p, phases, s);
+    if (p.Npad % 128 == 0) return launch_cfg<DT, 128, 128, 2, 2, 2>(p, phases, s);
+    if (p.Npad % 64 == 0) return launch_cfg<DT, 128, 64, 2, 2, 2>(p, phases, s);
+    return launch_cfg<DT, 128, 32, 4, 1, 2>(p, phases, s);
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t s)
