@@ -40,7 +40,9 @@ def cpu_baseline(size, frames=2):
     net = build_net("test", size, 21, 1024, 1, True, True)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
     sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
-    cores = os.cpu_count() or 1
+    # torch's CPU convs peak at ~16 threads on the 256-core GPU host (measured: 8/16/32/64/128 threads
+    # -> 0.066/0.046/0.065/0.20/0.40 s per trunk); all-core runs are 100x slower from oversubscription.
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = dict(feature_maps=[size // 8, size // 16, size // 32, size // 64], min_dim=size, steps=[8, 16, 32, 64],
                min_sizes=[32, 64, 128, 256], max_sizes=[], aspect_ratios=[[2]] * 4, variance=[0.1, 0.2], clip=True,
@@ -68,7 +70,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
 
     import torch

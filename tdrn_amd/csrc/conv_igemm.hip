@@ -29,6 +29,8 @@ struct ConvParams {
     int kh, kw, stride, pad, dil, relu, out_f32, out_vec;
     long long o_bs, o_rs, o_cs, o_base, o_pr, o_pc;
     int n_tiles, Ktot;
+    int out_linear;   // out element (m, c) at o_base + m*o_cs + c (plain NHWC tensor): no index decode
+    int ablate;   // diagnostics only (TDRN_CONV_ABLATE): 1 = skip the K-loop loads, 2 = skip the MFMAs
 };
 
 template <typename DT> struct Mma;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
 
     int tr = 0, tq = 0, c0 = 0, kofs = 0;   // current tap (row, col), channel offset, K offset
     auto stage = [&](int buf) {
+        if (p.ablate & 1) return;
         char *sb = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     const int wm = wave % WGM, wn = wave / WGM;
     const int prow0 = wm * (WP * 32) + r32, crow0 = wn * (WC * 32) + r32;
     auto compute = [&](int buf) {
+        if (p.ablate & 2) return;
         const char *wsb = smem + buf * STAGE;
         const char *psb = wsb + BN * 128;
 #pragma unroll
@@ -257,32 +261,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
         }
     } else {
         constexpr int P16 = elem_traits<DT>::per16;
-        constexpr int CPR = BN / P16;
-        for (int idx = t; idx < BM * CPR; idx += NT) {
-            const int row = idx / CPR, chn = idx - row * CPR;
-            const int m = m0 + row, c = n0 + chn * P16;
-            if (m >= p.M || c >= p.Cout) continue;
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            const long long eo = obase + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
-            float v[P16];
+        constexpr int CPR = BN / P16;              // 16-byte chunks per tile row
+        constexpr int RSTEP = NT / CPR;            // tile rows covered per pass
+        static_assert(NT % CPR == 0, "store mapping");
+        const int chn = t % CPR, c = n0 + chn * P16;
+        if (c < p.Cout) {
+            for (int row = t / CPR; row < BM; row += RSTEP) {
+                const int m = m0 + row;
+                if (m >= p.M) break;
+                long long eo;
+                if (p.out_linear) {
+                    eo = obase + (long long)m * p.o_cs + c;
+                } else {
+                    const int b = m / HoWo, rem = m - b * HoWo;
+                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    eo = obase + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
+                }
+                float v[P16];
 #pragma unroll
-            for (int q = 0; q < P16 / 4; ++q) {
-                const f32x4 x = *(const f32x4 *)(smem + row * CS + chn * (P16 * 4) + q * 16);
+                for (int q = 0; q < P16 / 4; ++q) {
+                    const f32x4 x = *(const f32x4 *)(smem + row * CS + chn * (P16 * 4) + q * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
+                    for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
+                }
+                if (p.res) {
+                    float rv[P16];
+                    unpack16<DT>(*(const u32x4 *)(p.res + eo * ES), rv);
+#pragma unroll
+                    for (int j = 0; j < P16; ++j) v[j] += rv[j];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < P16; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                *(u32x4 *)(p.out + eo * ES) = pack16<DT>(v);
             }
-            if (p.res) {
-                float rv[P16];
-                unpack16<DT>(*(const u32x4 *)(p.res + eo * ES), rv);
-#pragma unroll
-                for (int j = 0; j < P16; ++j) v[j] += rv[j];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < P16; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            *(u32x4 *)(p.out + eo * ES) = pack16<DT>(v);
         }
     }
 }
@@ -341,7 +354,12 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     p.out_vec = (a.out_f32 && a.o_bs % 4 == 0 && a.o_rs % 4 == 0 && a.o_cs % 4 == 0 && a.o_base % 4 == 0 &&
                  a.o_pr % 4 == 0 && a.o_pc % 4 == 0 && ((uintptr_t)a.out % 16 == 0)) ? 1 : 0;
     p.Ktot = a.kh * a.kw * a.Cin;
+    p.out_linear = (!a.out_f32 && a.phases == 1 && a.o_rs == (long long)a.Wo * a.o_cs &&
+                    a.o_bs == (long long)a.Ho * a.Wo * a.o_cs) ? 1 : 0;
     p.n_tiles = 0;
+    static int ablate = -1;
+    if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+    p.ablate = ablate;
     if (p.M <= 0) return TDRN_OK;
     switch (a.dtype) {
         case TDRN_F32: return launch_dt<float>(p, a.phases, s);

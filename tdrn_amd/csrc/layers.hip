@@ -20,39 +20,59 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict
 {
     constexpr int P16 = elem_traits<DT>::per16;
     constexpr int ES = elem_traits<DT>::bytes;
+    // 256 pixels x 64 channels per pass are transposed through LDS so that the block writes whole
+    // NHWC lines (a lane-per-pixel store touches 64 different 128-B lines per instruction and the
+    // memory side sees 2.75x the bytes: measured with WRITE_SIZE).
+    __shared__ __attribute__((aligned(16))) char tile[256 * (64 * ES + 16)];
+    constexpr int TS = 64 * ES + 16;            // padded LDS row stride
     const long long total = (long long)B * So * So;
-    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= total) return;
-    const int b = (int)(pix / (So * So));
-    const int rem = (int)(pix - (long long)b * So * So);
-    const int ho = rem / So, wo = rem - ho * So;
+    const long long pix0 = (long long)blockIdx.x * 256;
+    const long long pix = pix0 + threadIdx.x;
+    const bool live = pix < total;
     float v[27];
+    if (live) {
+        const int b = (int)(pix / (So * So));
+        const int rem = (int)(pix - (long long)b * So * So);
+        const int ho = rem / So, wo = rem - ho * So;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int hi = ho * stride - 1 + r, wi = wo * stride - 1 + q;
-                const bool ok = (unsigned)hi < (unsigned)S && (unsigned)wi < (unsigned)S;
-                v[c * 9 + r * 3 + q] = ok ? x[(((size_t)b * 3 + c) * S + hi) * S + wi] : 0.f;
+                for (int q = 0; q < 3; ++q) {
+                    const int hi = ho * stride - 1 + r, wi = wo * stride - 1 + q;
+                    const bool ok = (unsigned)hi < (unsigned)S && (unsigned)wi < (unsigned)S;
+                    v[c * 9 + r * 3 + q] = ok ? x[(((size_t)b * 3 + c) * S + hi) * S + wi] : 0.f;
+                }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = 0.f;
+    }
+    const int npix = (int)((total - pix0) < 256 ? (total - pix0) : 256);
+    for (int cb = 0; cb < Cpad; cb += 64) {
+        for (int c0 = 0; c0 < 64; c0 += P16) {
+            float o[P16];
+#pragma unroll
+            for (int j = 0; j < P16; ++j) {
+                const int co = cb + c0 + j;          // wave-uniform
+                float acc = 0.f;
+                if (co < Cout) {
+                    acc = bias[co];
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+                    if (relu) acc = fmaxf(acc, 0.f);
+                }
+                o[j] = acc;
             }
-    char *dst = out + (size_t)pix * Cpad * ES;
-    for (int c0 = 0; c0 < Cpad; c0 += P16) {
-        float o[P16];
-#pragma unroll
-        for (int j = 0; j < P16; ++j) {
-            const int co = c0 + j;          // wave-uniform
-            float acc = 0.f;
-            if (co < Cout) {
-                acc = bias[co];
-#pragma unroll
-                for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
-                if (relu) acc = fmaxf(acc, 0.f);
-            }
-            o[j] = acc;
+            *(u32x4 *)(tile + threadIdx.x * TS + c0 * ES) = pack16<DT>(o);
         }
-        *(u32x4 *)(dst + (size_t)c0 * ES) = pack16<DT>(o);
+        __syncthreads();
+        constexpr int CPR = 64 * ES / 16;           // 16-B chunks per pixel row of this channel block
+        for (int i = threadIdx.x; i < npix * CPR; i += 256) {
+            const int row = i / CPR, ch = i - row * CPR;
+            *(u32x4 *)(out + ((size_t)(pix0 + row) * Cpad + cb) * ES + ch * 16) = *(const u32x4 *)(tile + row * TS + ch * 16);
+        }
+        __syncthreads();
     }
 }
 
