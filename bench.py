@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
 
@@ -132,6 +133,10 @@ def main():
     eng.forward(x)
     torch.cuda.synchronize()
     stats = eng.kernel_stats()
+    if args.per_op and rank == 0:
+        for o in eng.op_stats():
+            tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
+            print("%-44s %8.1f us %8.1f GF %7.1f TF/s %7.2f GB" % (o["name"], o["ms"] * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
     eng.set_profile(False)
     conv = [s for s in stats if s["name"] == "conv_igemm_mfma"][0]
     peak = PEAK_TFLOPS[args.dtype]

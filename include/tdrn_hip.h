@@ -213,6 +213,8 @@ typedef struct {
 } tdrn_kernel_stat;
 TDRN_API int tdrn_net_profile(tdrn_net *net, int enable);
 TDRN_API int tdrn_net_kernel_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries);
+/* same accounting per launch of the last profiled forward (name = producing parameter / op kind) */
+TDRN_API int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries);
 
 /* Test / debug access to the plan's internal activation tensors (NHWC, net dtype) after a
  * forward on the same workspace: tdrn_net_tensor_info names tensor `index` after the parameter

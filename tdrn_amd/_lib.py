@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtdrn_hip.so")
+LIB_PATH = os.environ.get("TDRN_LIB_PATH") or os.path.join(_HERE, "lib", "libtdrn_hip.so")   # override: diagnostics builds only
 
 F32, BF16, F16 = 0, 1, 2
 DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp16": F16,
@@ -75,6 +75,7 @@ _SIGS = {
     "tdrn_net_read_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "tdrn_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "tdrn_net_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int]),
+    "tdrn_net_op_stats": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

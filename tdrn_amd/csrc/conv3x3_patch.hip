@@ -6,14 +6,17 @@
 // the matrix pipe: every one of the 9 taps re-stages the same activations, and all waves run the
 // same load->MFMA program in lockstep, so loads and MFMAs barely overlap (28 % MFMA utilisation).
 //
-// Structure (one 512-thread workgroup per CU, persistent over output tiles):
-//   * waves 4-7 = LOADERS.  Per 128-byte channel chunk they bring the input PATCH of the tile
+// Structure (one 768-thread workgroup per CU, persistent over output tiles; per SIMD: 2 consumer
+// waves + 1 loader wave):
+//   * waves 8-11 = LOADERS.  Per 128-byte channel chunk they bring the input PATCH of the tile
 //     (tile + 1-pixel halo, <= 352 rows of 128 B) into LDS once -- the 9 taps are then just shifted
 //     row addresses into that image -- plus the [BN x 128 B] weight slice of every (chunk, tap) step
 //     into a 3-slot ring, two steps ahead.  All by global_load_lds_dwordx4 with the bank swizzle on
 //     the source address; out-of-image rows read a zero page.  Waits are counted vmcnt(N).
-//   * waves 0-3 = CONSUMERS.  ds_read_b128 + v_mfma only: each owns 64 pixels x BN couts
-//     (2 x BN/32 accumulator tiles), weights as the A operand so a lane holds 4 consecutive couts
+//   * waves 0-7 = CONSUMERS.  ds_read_b128 + v_mfma only: each owns 64 pixels x BN/2 couts
+//     (2 x BN/64 accumulator tiles), operand fragments double-buffered in registers and the last
+//     K-slice of a step multiplied AFTER the step's barrier (covers the barrier and the first reads
+//     of the next step); weights as the A operand so a lane holds 4 consecutive couts
 //     of one pixel.  Epilogue per wave through a private LDS strip -> whole-line NHWC stores, with
 //     bias, ReLU and (optionally) the following 2x2 max-pool fused in registers.
 //   * one s_barrier per (chunk, tap) step; loaders run ahead across tile boundaries, so the next
@@ -27,6 +30,13 @@
 
 #include "kernels.h"
 
+// diagnostics build switch (never set in the product build): 1 = loaders issue nothing, 2 = consumers
+// skip ds_read + MFMA, 4 = skip the epilogue stores.  Compile-time on purpose: a runtime flag splits
+// the K loop into basic blocks and hipcc then waits lgkmcnt(0/1) where lgkmcnt(4) would do.
+#ifndef TDRN_PATCH_ABLATE
+#define TDRN_PATCH_ABLATE 0
+#endif
+
 namespace tdrn {
 
 struct PatchParams {
@@ -35,10 +45,11 @@ struct PatchParams {
     char *out, *out_pool;          // NHWC [B][H][W][Cs] and optional pooled [B][H/2][W/2][Cs]
     int B, H, W, Cin, Cout, Cs, Ktot;
     int relu;
-    int tw;                        // 32 / 16: 2-D tiles of (256/tw) x tw ; 0: flat tiles
+    int tw, lgtw;                  // 32 / 16: 2-D tiles of (256/tw) x tw ; 0: flat tiles
     int tiles_x, tiles_per_img;    // 2-D mode
     int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
     int M;                         // B*H*W
+    int ablate;                    // diagnostics (TDRN_CONV_ABLATE): 1 = loaders issue nothing, 2 = consumers skip ds_read+MFMA
 };
 
 namespace {
@@ -76,7 +87,8 @@ __device__ __forceinline__ void wait_vmcnt(int n)   // n is wave-uniform
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     }
 }
 
@@ -84,104 +96,89 @@ constexpr int kPatchSlots = 44;                 // 8-row LDS-DMA pieces per patc
 constexpr int kPatchBytes = kPatchSlots * 1024;
 constexpr int kSlotsPerLoader = kPatchSlots / 4;
 
-// position of the persistent workgroup in the (item, chunk, tap) step sequence
-struct Cursor {
-    int it, item, cc, tap;      // iteration, work item (m_tile, n_tile), channel chunk, tap 0..8
-    bool valid;
-};
-
 }  // namespace
 
-template <typename DT, int BN>
-__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchParams p)
+template <typename DT, int BN, bool FLAT>
+__global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 {
     constexpr int ES = elem_traits<DT>::bytes;
     constexpr int P16 = elem_traits<DT>::per16;
     constexpr int CK = 128 / ES;
-    constexpr int WC = BN / 32;                         // cout tiles per consumer
+    constexpr int BNH = BN / 2;                         // couts per consumer wave (8 consumers = 4 pixel groups x 2 cout halves)
+    constexpr int WC = BNH / 32;                        // cout tiles per consumer
     constexpr int WBYTES = BN * 128;                    // one weight slot
     constexpr int WL = BN / 32;                         // weight LDS-DMA pieces per loader wave per step
     constexpr int SROWS = ES == 2 ? 16 : 8;             // pixels per epilogue round (per wave)
-    constexpr int SSTRIDE = BN * ES + 16;               // staging row stride (bytes)
+    constexpr int SSTRIDE = BNH * ES + 16;              // staging row stride (bytes)
     constexpr int OFF_W = 2 * kPatchBytes;
     constexpr int OFF_S = OFF_W + 3 * WBYTES;
-    constexpr int LDS = OFF_S + 4 * SROWS * SSTRIDE;
+    constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the current item (one LDS-DMA piece)
+    constexpr int LDS = OFF_B + 1024;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nchunks = p.Cin / CK;
-    const int G = gridDim.x;
 
     // ---- work distribution: each XCD (blockIdx % 8) owns a contiguous range of items so that cout
-    // siblings of a pixel tile and neighbouring tiles share its L2.
+    // siblings of a pixel tile and neighbouring tiles share its L2.  This workgroup runs items
+    // item0, item0 + istride, ... (n_it of them); the step sequence is (item, chunk, tap).
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_xcd = (p.items + 7) >> 3, cus_per_xcd = (G + 7) >> 3;
-    auto item_of = [&](int it) -> int {
-        const int local = it * cus_per_xcd + slot;
-        if (local >= per_xcd) return -1;
-        const int item = xcd * per_xcd + local;
-        return item < p.items ? item : -1;
-    };
-    auto first = [&]() {
-        Cursor c;
-        c.it = 0; c.item = item_of(0); c.cc = 0; c.tap = 0; c.valid = c.item >= 0;
-        return c;
-    };
-    auto step = [&](Cursor &c) {           // advance by one (chunk, tap) step
-        if (!c.valid) return;
-        if (++c.tap == 9) {
-            c.tap = 0;
-            if (++c.cc == nchunks) {
-                c.cc = 0;
-                ++c.it;
-                c.item = item_of(c.it);
-                c.valid = c.item >= 0;
-            }
-        }
-    };
-    auto next_chunk = [&](Cursor &c) {     // advance to the first step of the next chunk
-        if (!c.valid) return;
-        c.tap = 0;
-        if (++c.cc == nchunks) {
-            c.cc = 0;
-            ++c.it;
-            c.item = item_of(c.it);
-            c.valid = c.item >= 0;
-        }
-    };
-
+    const int per_xcd = (p.items + 7) >> 3, istride = ((int)gridDim.x + 7) >> 3;
+    int avail = p.items - xcd * per_xcd;
+    avail = avail < per_xcd ? avail : per_xcd;
+    const int n_it = avail > slot ? (avail - slot + istride - 1) / istride : 0;
+    const int item0 = xcd * per_xcd + slot;
+    const int n_steps = n_it * nchunks * 9;
     const int RS = p.tw ? p.tw + 2 : p.W;              // patch row stride of one image row
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // =========================== LOADER ===========================
-        const int lw = wave - 4;
+        const int lw = wave - 8;
         const int lrow = lane >> 3, pc = lane & 7;
         unsigned poff[kSlotsPerLoader];                 // byte offset of my 16 B in the tensor, or ~0u
-        int poff_item = -2;
-        auto patch_table = [&](int item) {
-            const int mt = item / p.n_tiles;
-            if (mt == poff_item) return;
-            poff_item = mt;
+        int pyx[kSlotsPerLoader];                       // (py << 16 | px) of my patch row, -1 = beyond the patch
+        int plc[kSlotsPerLoader];                       // swizzled 16-B chunk offset inside the 128-B row
+        {
+            const int th = p.tw ? 256 / p.tw : 0;
 #pragma unroll
             for (int j = 0; j < kSlotsPerLoader; ++j) {
                 const int pr = (lw + 4 * j) * 8 + lrow;
-                const int lc16 = (pc ^ ((pr >> 1) & 7)) << 4;
-                long long pix = -1;
+                plc[j] = (pc ^ ((pr >> 1) & 7)) << 4;
                 if (p.tw) {
-                    const int th = 256 / p.tw;
-                    const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
-                    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
                     const int py = pr / RS, px = pr - py * RS;
-                    const int y = ty * th - 1 + py, x = tx * p.tw - 1 + px;
-                    if (py < th + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                        pix = ((long long)b * p.H + y) * p.W + x;
+                    pyx[j] = py < th + 2 ? ((py << 16) | px) : -1;
                 } else {
-                    const long long j0 = (long long)mt * 256 - p.W - 1 + pr;
-                    if (pr < 256 + 2 * p.W + 2 && j0 >= 0 && j0 < p.M) pix = j0;
+                    pyx[j] = pr < 256 + 2 * p.W + 2 ? pr : -1;
                 }
-                poff[j] = pix < 0 ? 0xFFFFFFFFu : (unsigned)(pix * p.Cin * ES + lc16);
+            }
+        }
+        int table_mt = -1;
+        auto patch_table = [&](int item) {              // per pixel tile: where my patch rows live
+            const int mt = item / p.n_tiles;
+            if (mt == table_mt) return;
+            table_mt = mt;
+            const long long rowbytes = (long long)p.Cin * ES;
+            if (p.tw) {
+                const int th = 256 / p.tw;
+                const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
+                const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+                const int y0 = ty * th - 1, x0 = tx * p.tw - 1;
+#pragma unroll
+                for (int j = 0; j < kSlotsPerLoader; ++j) {
+                    const int y = y0 + (pyx[j] >> 16), x = x0 + (pyx[j] & 0xffff);
+                    const bool ok = pyx[j] >= 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    poff[j] = ok ? (unsigned)((((long long)b * p.H + y) * p.W + x) * rowbytes + plc[j]) : 0xFFFFFFFFu;
+                }
+            } else {
+                const long long j0 = (long long)mt * 256 - p.W - 1;
+#pragma unroll
+                for (int j = 0; j < kSlotsPerLoader; ++j) {
+                    const long long pix = j0 + pyx[j];
+                    const bool ok = pyx[j] >= 0 && pix >= 0 && pix < p.M;
+                    poff[j] = ok ? (unsigned)(pix * rowbytes + plc[j]) : 0xFFFFFFFFu;
+                }
             }
         };
         unsigned woff[WL];                              // weight row part of the source offset
@@ -190,289 +187,370 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchParams p)
             const int n = (lw + 4 * k) * 8 + lrow;
             woff[k] = (unsigned)((size_t)n * p.Ktot * ES + ((pc ^ ((n >> 1) & 7)) << 4));
         }
-        auto load_weights = [&](const Cursor &c, int sidx) {     // step sidx -> ring slot sidx % 3
-            char *dst = smem + OFF_W + (sidx % 3) * WBYTES;
-            const int nt = c.item % p.n_tiles;
-            const char *src = p.w + ((size_t)nt * BN * p.Ktot + (size_t)c.tap * p.Cin + (size_t)c.cc * CK) * ES;
+        constexpr bool live = !(TDRN_PATCH_ABLATE & 1);
+        // weight stream state: step index ws, (w_it, w_cc, w_tap), source = wbase + wk
+        int ws = 0, w_it = 0, w_cc = 0, w_tap = 0, wslot = 0;
+        const char *wbase = p.w;
+        unsigned wk = 0;
+        auto weight_item = [&]() { wbase = p.w + (size_t)((item0 + w_it * istride) % p.n_tiles) * BN * p.Ktot * ES; };
+        constexpr bool wfixed = (TDRN_PATCH_ABLATE & 16) != 0, pfixed = (TDRN_PATCH_ABLATE & 32) != 0;
+        auto load_weights = [&]() {                     // issue step ws into ring slot wslot, then advance
+            if (live) {
+                char *dst = smem + OFF_W + wslot * WBYTES;
 #pragma unroll
-            for (int k = 0; k < WL; ++k) glds(src + woff[k], dst + (lw + 4 * k) * 1024);
+                for (int k = 0; k < WL; ++k) glds(wfixed ? p.w + (woff[k] & 0xffffu) : wbase + wk + woff[k], dst + (lw + 4 * k) * 1024);
+            }
+            ++ws;
+            wslot = wslot == 2 ? 0 : wslot + 1;
+            wk += (unsigned)(p.Cin * ES);
+            if (++w_tap == 9) {
+                w_tap = 0;
+                if (++w_cc == nchunks) {
+                    w_cc = 0;
+                    ++w_it;
+                    if (w_it < n_it) weight_item();
+                }
+                wk = (unsigned)(w_cc * 128);
+            }
         };
-        auto load_patch_slot = [&](int cc, int buf, int j) {
+        auto load_patch = [&](int j, unsigned ccoff, char *dstbuf) {
+            if (!live) return;
             const unsigned o = poff[j];
-            glds(o == 0xFFFFFFFFu ? p.zero : p.in + (size_t)o + (size_t)cc * 128, smem + buf * kPatchBytes + (lw + 4 * j) * 1024);
+            glds(o == 0xFFFFFFFFu ? p.zero : (pfixed ? p.in + (o & 0xfffffu) : p.in + (size_t)o + ccoff), dstbuf + (lw + 4 * j) * 1024);
+        };
+        // patch stream state: the chunk being PREFETCHED: (p_it, p_cc), buffer pbuf
+        int p_it = 0, p_cc = 0, pbuf = 0;
+        auto next_patch_chunk = [&]() {
+            pbuf ^= 1;
+            if (++p_cc == nchunks) {
+                p_cc = 0;
+                ++p_it;
+            }
         };
 
-        Cursor wc = first();            // weights cursor (runs 2 steps ahead)
-        Cursor pcur = first();          // patch cursor (runs 1 chunk ahead)
-        int chunk_no = 0;               // global chunk counter of the patch cursor (buffer = chunk_no & 1)
-        if (pcur.valid) {
-            patch_table(pcur.item);
+        if (n_it > 0) {
+            weight_item();
+            patch_table(item0);
 #pragma unroll
-            for (int j = 0; j < kSlotsPerLoader; ++j) load_patch_slot(pcur.cc, 0, j);
-            load_weights(wc, 0);
-            step(wc);
-            if (wc.valid) load_weights(wc, 1);
-            step(wc);
+            for (int j = 0; j < kSlotsPerLoader; ++j) load_patch(j, 0u, smem);
+            load_weights();
+            if (n_steps > 1) load_weights();
+            next_patch_chunk();
         }
-        next_chunk(pcur);
-        chunk_no = 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        Cursor cur = first();
-        for (int s = 0; cur.valid; ++s) {
-            // operands of step s are in LDS.  Issue: weights of step s+2, and this tap's share of the
-            // next chunk's patch (taps 0-4: two pieces, tap 5: one).
+        int tap = 0, c_it = 0, c_cc = 0;
+        for (int g = 0; g < n_steps; ++g) {
+            // operands of step g are in LDS.  Issue the weights of step g+2 and this tap's share of the
+            // NEXT chunk's patch (taps 0-4: two pieces, tap 5: one); then make sure everything issued
+            // before this step has landed, and release the step.
             int issued = 0;
-            if (wc.valid) {
-                load_weights(wc, s + 2);
-                issued += WL;
+            if (ws < n_steps) {
+                load_weights();
+                issued = WL;
             }
-            step(wc);
-            if (pcur.valid) {
-                if (cur.tap == 0) patch_table(pcur.item);
-                // static register indices (a runtime-indexed poff[] would live in scratch)
-#pragma unroll
-                for (int j = 0; j < kSlotsPerLoader; ++j)
-                    if ((j >> 1) == cur.tap) {
-                        load_patch_slot(pcur.cc, chunk_no & 1, j);
-                        ++issued;
-                    }
+            if (p_it < n_it && tap < 6) {
+                char *dstbuf = smem + pbuf * kPatchBytes;
+                const unsigned ccoff = (unsigned)(p_cc * 128);
+                switch (tap) {
+                    case 0:
+                        patch_table(item0 + p_it * istride);
+                        load_patch(0, ccoff, dstbuf); load_patch(1, ccoff, dstbuf); issued += 2; break;
+                    case 1: load_patch(2, ccoff, dstbuf); load_patch(3, ccoff, dstbuf); issued += 2; break;
+                    case 2: load_patch(4, ccoff, dstbuf); load_patch(5, ccoff, dstbuf); issued += 2; break;
+                    case 3: load_patch(6, ccoff, dstbuf); load_patch(7, ccoff, dstbuf); issued += 2; break;
+                    case 4: load_patch(8, ccoff, dstbuf); load_patch(9, ccoff, dstbuf); issued += 2; break;
+                    default: load_patch(10, ccoff, dstbuf); issued += 1; break;
+                }
             }
-            if (cur.tap == 8) {
-                next_chunk(pcur);
-                ++chunk_no;
+            if (lw == 0 && c_cc == 0 && tap == 6) {
+                // the current item's bias -> LDS (read by the consumers' epilogue; the previous item's
+                // epilogue ended before this item's first barrier)
+                const int nt = (item0 + c_it * istride) % p.n_tiles;
+                if (live) glds(lane < BN / 4 ? (const char *)(p.bias + nt * BN) + lane * 16 : p.zero, smem + OFF_B);
+                issued += 1;
             }
-            // everything issued BEFORE this step (weights of s+1, older patch pieces) must have landed
-            wait_vmcnt(issued);
+            wait_vmcnt(live ? issued : 0);
             __builtin_amdgcn_s_barrier();
-            step(cur);
+            if (++tap == 9) {
+                tap = 0;
+                next_patch_chunk();
+                if (++c_cc == nchunks) {
+                    c_cc = 0;
+                    ++c_it;
+                }
+            }
         }
         return;
     }
 
     // =========================== CONSUMER ===========================
     const int r32 = lane & 31, hh = lane >> 5;
-    const int cw = wave;                               // consumer index 0..3: pixels [64*cw, 64*cw+64)
-    char *stg = smem + OFF_S + cw * SROWS * SSTRIDE;
+    const int cw = wave & 3;                           // pixel group: pixels [64*cw, 64*cw+64)
+    const int chalf = wave >> 2;                       // cout half: couts [BNH*chalf, BNH*chalf + BNH) of the tile
+    char *stg = smem + OFF_S + wave * SROWS * SSTRIDE;
     f32x16 acc[WC][2];
 
     int base_i[2];                                      // patch row of tap (0,0) for my two pixel tiles
     unsigned tapmask[2] = {0x1FFu, 0x1FFu};             // flat mode: bit t = tap t inside the image
     unsigned need_mask = 0;                             // wave-uniform: taps where some lane is masked
-    int cur_item = -2;
-    auto setup_item = [&](int item) {
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int i = cw * 64 + pt * 32 + r32;          // tile-local pixel
+        base_i[pt] = p.tw ? (i >> p.lgtw) * RS + (i & (p.tw - 1)) : i;
+    }
+    const int wsw = (r32 >> 1) & 7;                     // swizzle of my weight rows (row = 32*ci + r32)
+    constexpr int CPR = BNH * ES / 16;                  // 16-B chunks per pixel (my cout half)
+    constexpr int RPI = 64 / CPR;                       // staging rows copied per wave pass
+    const int my_ch = lane % CPR, my_row = lane / CPR;
+    constexpr bool compute = !(TDRN_PATCH_ABLATE & 2);
+
+    // ---- per-item state ---------------------------------------------------------------------------
+    int cur_mt = -1, n0 = 0;
+    long long tile_pix0 = 0;                            // 2-D: global pixel of the tile's (0,0); flat: mt*256
+    auto setup_item = [&](int it) {
+        const int item = item0 + it * istride;
         const int mt = item / p.n_tiles;
-        if (mt == cur_item) return;
-        cur_item = mt;
+        n0 = (item - mt * p.n_tiles) * BN;
+        if (mt == cur_mt) return;
+        cur_mt = mt;
+        if (p.tw) {
+            const int th = 256 / p.tw;
+            const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
+            const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+            tile_pix0 = ((long long)b * p.H + ty * th) * p.W + tx * p.tw;
+            return;
+        }
+        tile_pix0 = (long long)mt * 256;
         need_mask = 0;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const int i = cw * 64 + pt * 32 + r32;      // tile-local pixel
-            if (p.tw) {
-                const int ty = i / p.tw, tx = i - ty * p.tw;
-                base_i[pt] = ty * RS + tx;
-            } else {
-                base_i[pt] = i;
-                const long long m = (long long)mt * 256 + i;
-                unsigned mk = 0;
-                if (m < p.M) {
-                    const int rem = (int)(m % ((long long)p.H * p.W));
-                    const int y = rem / p.W, x = rem - y * p.W;
+            const long long m = tile_pix0 + cw * 64 + pt * 32 + r32;
+            unsigned mk = 0;
+            if (m < p.M) {
+                const int rem = (int)(m % ((long long)p.H * p.W));
+                const int y = rem / p.W, x = rem - y * p.W;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mk |= 1u << t;
-                    }
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mk |= 1u << t;
                 }
-                tapmask[pt] = mk;
-                unsigned bad = ~mk & 0x1FFu;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) bad |= __shfl_xor(bad, o, 64);
-                need_mask |= bad;
             }
+            tapmask[pt] = mk;
+            unsigned bad = ~mk & 0x1FFu;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) bad |= __shfl_xor(bad, o, 64);
+            need_mask |= bad;
         }
         need_mask = __builtin_amdgcn_readfirstlane(need_mask);
     };
 
-    const int wsw = (r32 >> 1) & 7;                     // swizzle of my weight rows (row = 32*ci + r32)
+    // ---- epilogue of one item (wave-private staging strip -> whole-line stores) -------------------
+    auto epilogue = [&]() {
+        const int my_c = n0 + chalf * BNH + my_ch * P16;
+        auto pixel_of = [&](int i) -> long long {       // global pixel of tile-local pixel i (or -1)
+            if (p.tw) return tile_pix0 + (long long)(i >> p.lgtw) * p.W + (i & (p.tw - 1));
+            const long long m = tile_pix0 + i;
+            return m < p.M ? m : -1;
+        };
+        // one 4-cout quad of one accumulator tile -> (+bias, ReLU, convert) -> staging row
+        auto stage_quad = [&](const f32x16 &t, int ci, int g, int srow) {
+            const f32x4 bv = *(const f32x4 *)(smem + OFF_B + (chalf * BNH + ci * 32 + 8 * g + 4 * hh) * 4);
+            float q4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = t[4 * g + j] + bv[j];
+                q4[j] = p.relu ? fmaxf(v, 0.f) : v;
+            }
+            char *d = stg + srow * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * ES;
+            if constexpr (ES == 4) {
+                *(f32x4 *)d = f32x4{q4[0], q4[1], q4[2], q4[3]};
+            } else {
+                const unsigned lo = (unsigned)from_f32<DT>(q4[0]).v | ((unsigned)from_f32<DT>(q4[1]).v << 16);
+                const unsigned hi = (unsigned)from_f32<DT>(q4[2]).v | ((unsigned)from_f32<DT>(q4[3]).v << 16);
+                *(uint2 *)d = make_uint2(lo, hi);
+            }
+        };
+        if (p.out && !(TDRN_PATCH_ABLATE & 4)) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll 1
+                for (int rd = 0; rd < 32 / SROWS; ++rd) {
+                    if (r32 / SROWS == rd) {            // lanes whose pixel is in this round
+#pragma unroll
+                        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, r32 % SROWS);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): my LDS writes are done
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < SROWS / RPI; ++k) {
+                        const int row = my_row + k * RPI;
+                        const long long gp = pixel_of(cw * 64 + pt * 32 + rd * SROWS + row);
+                        if (gp >= 0 && my_c < p.Cout)
+                            *(u32x4 *)(p.out + ((size_t)gp * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
+                    }
+                    __builtin_amdgcn_wave_barrier();     // (a wave's DS instructions execute in order)
+                }
+            }
+        }
+        if (p.out_pool) {
+            // fused MaxPool2d(2,2) on the RAW accumulators (max commutes with the monotonic bias+ReLU
+            // applied at staging): the partner row is my other pixel tile (tw = 32) or lane^16
+            // (tw = 16); the partner column is lane^1.  Even-x lanes of the top row hold the result.
+            const int PW = p.W >> 1;
+            const int npool = p.tw == 32 ? 16 : 8;      // pooled pixels per pixel tile
+            const bool holder = (r32 & 1) == 0 && (p.tw == 32 || r32 < 16);
+            const int prow_l = r32 >> 1;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                if (p.tw == 32 && pt == 1) break;
+#pragma unroll
+                for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[ci][pt][e];
+                        if (p.tw == 32) v = fmaxf(v, acc[ci][1][e]);
+                        else v = fmaxf(v, __shfl_xor(v, 16, 64));
+                        v = fmaxf(v, __shfl_xor(v, 1, 64));
+                        acc[ci][pt][e] = v;
+                    }
+#pragma unroll 1
+                for (int rd = 0; rd < (npool + SROWS - 1) / SROWS; ++rd) {
+                    if (holder && prow_l / SROWS == rd) {
+#pragma unroll
+                        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, prow_l % SROWS);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_wave_barrier();
+                    const int rows_here = (npool - rd * SROWS) < SROWS ? (npool - rd * SROWS) : SROWS;
+#pragma unroll
+                    for (int k = 0; k < SROWS / RPI; ++k) {
+                        const int row = my_row + k * RPI;
+                        if (row < rows_here && my_c < p.Cout) {
+                            const int pl = rd * SROWS + row;            // pooled pixel within this pixel tile
+                            const int i0 = cw * 64 + pt * 32 + 2 * pl;  // top-left pixel of the 2x2 window
+                            const long long g0 = tile_pix0 + (long long)(i0 >> p.lgtw) * p.W + (i0 & (p.tw - 1));
+                            // g0 = (b*H + y)*W + x with y, x even  ->  pooled index ((b*H + y)/2)*PW + x/2
+                            const long long bh = g0 / p.W;
+                            const int x = (int)(g0 - bh * p.W);
+                            const long long gpool = (bh >> 1) * PW + (x >> 1);
+                            *(u32x4 *)(p.out_pool + ((size_t)gpool * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    };
+
+    // ---- operand fragments: explicit double buffering (A/B sets) so that the reads of K-slice kk+1
+    // are in flight during the MFMAs of kk; the step's LAST slice is multiplied after the barrier,
+    // covering the barrier and the first reads of the next step.
+    u32x4 wfA[WC], pfA[2], wfB[WC], pfB[2];
+    const char *wsb = smem + OFF_W;
+    const char *psb = smem;
+    int prow[2] = {base_i[0], base_i[1]};
+    int psw[2] = {(base_i[0] >> 1) & 7, (base_i[1] >> 1) & 7};
+    auto load_frags = [&](u32x4 *wf, u32x4 *pf, int kk) {
+        if (!compute) return;
+        const int lc = 2 * kk + hh;
+#pragma unroll
+        for (int ci = 0; ci < WC; ++ci) wf[ci] = *(const u32x4 *)(wsb + (chalf * BNH + ci * 32 + r32) * 128 + ((lc ^ wsw) << 4));
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) pf[pt] = *(const u32x4 *)(psb + prow[pt] * 128 + ((lc ^ psw[pt]) << 4));
+    };
+    // m0/m1: all-ones, or zero for lanes whose tap falls outside the image (flat tiles only; branch-free)
+    auto mma_frags = [&](const u32x4 *wf, u32x4 *pf, unsigned m0, unsigned m1) {
+        if (!compute) return;
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf[0][j] &= m0;
+                pf[1][j] &= m1;
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) MmaP<DT>::run(wf[ci], pf[pt], acc[ci][pt]);
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ci][pt][e] = 0.f;
+    };
 
     __builtin_amdgcn_s_barrier();                       // prologue operands landed
-    Cursor cur = first();
-    int chunk_no = 0;
-    for (int s = 0; cur.valid; ++s) {
-        if (cur.cc == 0 && cur.tap == 0) {
-            setup_item(cur.item);
-#pragma unroll
-            for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[ci][pt][e] = 0.f;
+    if (n_it > 0) {
+        setup_item(0);
+        zero_acc();
+        load_frags(wfA, pfA, 0);
+    }
+    int it = 0, cc = 0, tap = 0, tq = 0, delta = 0, wslot = 0, pbuf = 0;
+#pragma unroll 1
+    for (int g = 0; g < n_steps; ++g) {
+        unsigned m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+        if constexpr (FLAT) {
+            m0 = ((tapmask[0] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
+            m1 = ((tapmask[1] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
         }
-        const char *wsb = smem + OFF_W + (s % 3) * WBYTES;
-        const char *psb = smem + (chunk_no & 1) * kPatchBytes;
-        const int tr = cur.tap / 3, tq = cur.tap - tr * 3;
-        const int delta = tr * RS + tq;
-        int prow[2], psw[2];
+        __builtin_amdgcn_s_setprio(1);
+        load_frags(wfB, pfB, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags(wfA, pfA, m0, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(wfA, pfA, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags(wfB, pfB, m0, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(wfB, pfB, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags(wfA, pfA, m0, m1);
+        __builtin_amdgcn_s_setprio(0);
+        // every LDS read of this step has returned -> the step's buffers may be refilled after the barrier
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        // ---- advance to step g+1 and start its first reads, THEN finish this step's last K-slice ----
+        const bool item_done = tap == 8 && cc == nchunks - 1;
+        wslot = wslot == 2 ? 0 : wslot + 1;
+        ++tap;
+        if (++tq == 3) {
+            tq = 0;
+            delta += RS;
+        }
+        if (tap == 9) {
+            tap = 0; tq = 0; delta = 0;
+            pbuf ^= 1;
+            if (++cc == nchunks) cc = 0;
+        }
+        wsb = smem + OFF_W + wslot * WBYTES;
+        psb = smem + pbuf * kPatchBytes;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            prow[pt] = base_i[pt] + delta;
+            prow[pt] = base_i[pt] + delta + tq;
             psw[pt] = (prow[pt] >> 1) & 7;
         }
-        const bool masked = (need_mask >> cur.tap) & 1u;
+        load_frags(wfA, pfA, 0);     // (past the last step this reads stale but in-bounds LDS; unused)
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int lc = 2 * kk + hh;
-            u32x4 wf[WC], pf[2];
-#pragma unroll
-            for (int ci = 0; ci < WC; ++ci) wf[ci] = *(const u32x4 *)(wsb + (ci * 32 + r32) * 128 + ((lc ^ wsw) << 4));
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) pf[pt] = *(const u32x4 *)(psb + prow[pt] * 128 + ((lc ^ psw[pt]) << 4));
-            if (masked) {
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
-                    if (!((tapmask[pt] >> cur.tap) & 1u)) pf[pt] = u32x4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) MmaP<DT>::run(wf[ci], pf[pt], acc[ci][pt]);
-        }
+        mma_frags(wfB, pfB, m0, m1);
         __builtin_amdgcn_s_setprio(0);
-
-        if (cur.tap == 8 && cur.cc == nchunks - 1) {
-            // ---------------- epilogue of this item (wave-private) ----------------
-            const int mt = cur.item / p.n_tiles, nt = cur.item - mt * p.n_tiles;
-            const int n0 = nt * BN;
-            // bias (+ReLU) in registers
-#pragma unroll
-            for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bv = *(const f32x4 *)(p.bias + n0 + ci * 32 + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float v = acc[ci][pt][4 * g + j] + bv[j];
-                            acc[ci][pt][4 * g + j] = p.relu ? fmaxf(v, 0.f) : v;
-                        }
-                }
-            // global pixel index of tile-local pixel i (or -1)
-            auto pixel_of = [&](int i) -> long long {
-                if (p.tw) {
-                    const int th = 256 / p.tw;
-                    const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
-                    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-                    const int y = ty * th + i / p.tw, x = tx * p.tw + i % p.tw;
-                    return ((long long)b * p.H + y) * p.W + x;
-                }
-                const long long m = (long long)mt * 256 + i;
-                return m < p.M ? m : -1;
-            };
-            constexpr int CPR = BN * ES / 16;           // 16-B chunks per pixel
-            if (p.out) {
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll
-                    for (int rd = 0; rd < 32 / SROWS; ++rd) {
-                        // lanes whose pixel is in this round write their 4-cout quads
-                        if (r32 / SROWS == rd) {
-#pragma unroll
-                            for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    float q4[4] = {acc[ci][pt][4 * g], acc[ci][pt][4 * g + 1], acc[ci][pt][4 * g + 2], acc[ci][pt][4 * g + 3]};
-                                    char *d = stg + (r32 % SROWS) * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * ES;
-                                    if constexpr (ES == 4) {
-                                        *(f32x4 *)d = f32x4{q4[0], q4[1], q4[2], q4[3]};
-                                    } else {
-                                        unsigned lo = (unsigned)from_f32<DT>(q4[0]).v | ((unsigned)from_f32<DT>(q4[1]).v << 16);
-                                        unsigned hi = (unsigned)from_f32<DT>(q4[2]).v | ((unsigned)from_f32<DT>(q4[3]).v << 16);
-                                        *(uint2 *)d = make_uint2(lo, hi);
-                                    }
-                                }
-                        }
-                        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): my LDS writes are done
-                        __builtin_amdgcn_wave_barrier();
-                        for (int idx = lane; idx < SROWS * CPR; idx += 64) {
-                            const int row = idx / CPR, ch = idx - row * CPR;
-                            const long long gp = pixel_of(cw * 64 + pt * 32 + rd * SROWS + row);
-                            const int c = n0 + ch * P16;
-                            if (gp >= 0 && c < p.Cout)
-                                *(u32x4 *)(p.out + ((size_t)gp * p.Cs + c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + ch * 16);
-                        }
-                        __builtin_amdgcn_s_waitcnt(0xC07F);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-            }
-            if (p.out_pool) {
-                // fused MaxPool2d(2,2): the partner row is my other pixel tile (tw = 32) or lane^16
-                // (tw = 16); the partner column is lane^1.  Even-x lanes of the top row hold the result.
-                const int PW = p.W >> 1, PH = p.H >> 1;
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    if (p.tw == 32 && pt == 1) break;
-#pragma unroll
-                    for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float v = acc[ci][pt][e];
-                            if (p.tw == 32) v = fmaxf(v, acc[ci][1][e]);
-                            else v = fmaxf(v, __shfl_xor(v, 16, 64));
-                            v = fmaxf(v, __shfl_xor(v, 1, 64));
-                            acc[ci][pt][e] = v;
-                        }
-                    // pooled pixels of this pixel tile: tw=32 -> 16 (one row); tw=16 -> 8 (lanes 0-15, even x)
-                    const int npool = p.tw == 32 ? 16 : 8;
-                    const bool holder = (r32 & 1) == 0 && (p.tw == 32 || r32 < 16);
-                    const int prow_l = p.tw == 32 ? (r32 >> 1) : (r32 >> 1);   // 0..15 / 0..7
-                    for (int rd = 0; rd < (npool + SROWS - 1) / SROWS; ++rd) {
-                        if (holder && prow_l / SROWS == rd) {
-#pragma unroll
-                            for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    float q4[4] = {acc[ci][pt][4 * g], acc[ci][pt][4 * g + 1], acc[ci][pt][4 * g + 2], acc[ci][pt][4 * g + 3]};
-                                    char *d = stg + (prow_l % SROWS) * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * ES;
-                                    if constexpr (ES == 4) {
-                                        *(f32x4 *)d = f32x4{q4[0], q4[1], q4[2], q4[3]};
-                                    } else {
-                                        unsigned lo = (unsigned)from_f32<DT>(q4[0]).v | ((unsigned)from_f32<DT>(q4[1]).v << 16);
-                                        unsigned hi = (unsigned)from_f32<DT>(q4[2]).v | ((unsigned)from_f32<DT>(q4[3]).v << 16);
-                                        *(uint2 *)d = make_uint2(lo, hi);
-                                    }
-                                }
-                        }
-                        __builtin_amdgcn_s_waitcnt(0xC07F);
-                        __builtin_amdgcn_wave_barrier();
-                        const int rows_here = (npool - rd * SROWS) < SROWS ? (npool - rd * SROWS) : SROWS;
-                        for (int idx = lane; idx < rows_here * CPR; idx += 64) {
-                            const int row = idx / CPR, ch = idx - row * CPR;
-                            const int pl = rd * SROWS + row;                    // pooled pixel within the tile row
-                            // tile-local coordinates of the 2x2 window's top-left pixel
-                            const int i0 = cw * 64 + pt * 32 + (p.tw == 32 ? 2 * pl : 2 * pl);
-                            const int th = 256 / p.tw;
-                            const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
-                            const int tyt = tt / p.tiles_x, txt = tt - tyt * p.tiles_x;
-                            const int y = tyt * th + i0 / p.tw, x = txt * p.tw + i0 % p.tw;
-                            const int c = n0 + ch * P16;
-                            if (c < p.Cout)
-                                *(u32x4 *)(p.out_pool + ((((size_t)b * PH + (y >> 1)) * PW + (x >> 1)) * p.Cs + c) * ES) =
-                                    *(const u32x4 *)(stg + row * SSTRIDE + ch * 16);
-                        }
-                        __builtin_amdgcn_s_waitcnt(0xC07F);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
+        if (item_done) {
+            epilogue();
+            ++it;
+            if (it < n_it) {
+                setup_item(it);
+                zero_acc();
             }
         }
-        if (cur.tap == 8) ++chunk_no;
-        __builtin_amdgcn_s_barrier();
-        step(cur);
     }
 }
 
@@ -493,9 +571,11 @@ int patch_conv_supported(const ConvArgs &a)
 
 template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p, hipStream_t s)
 {
+    const bool flat = p.tw == 0;
     // a multiple of 8 workgroups (the item split is per XCD); surplus workgroups find no item and exit
     const int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN>), dim3(grid), dim3(512), 0, s, p);
+    if (flat) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, true>), dim3(grid), dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, false>), dim3(grid), dim3(768), 0, s, p);
     return hip_status(hipGetLastError());
 }
 
@@ -511,6 +591,7 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     p.B = a.B; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.Cs = (int)a.o_cs; p.Ktot = 9 * a.Cin;
     p.relu = a.relu;
     p.tw = mode > 0 ? mode : 0;
+    p.lgtw = mode == 32 ? 5 : (mode == 16 ? 4 : 0);
     p.M = a.B * a.H * a.W;
     if (p.tw) {
         p.tiles_x = a.W / p.tw;
@@ -523,6 +604,9 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     const int BN = a.Npad % 128 == 0 ? 128 : 64;
     p.n_tiles = a.Npad / BN;
     p.items = p.m_tiles * p.n_tiles;
+    static int ablate = -1;
+    if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+    p.ablate = ablate;
     if (p.items <= 0) return TDRN_OK;
 #define LP(DT)                                                    \
     return BN == 128 ? launch_patch_cfg<DT, 128>(p, s) : launch_patch_cfg<DT, 64>(p, s)

@@ -364,10 +364,10 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     // 3x3/s1/p1 layers with enough tiles go to the warp-specialised patch kernel (TDRN_CONV_PATCH=0: off)
     static int use_patch = -1;
     if (use_patch < 0) { const char *e = getenv("TDRN_CONV_PATCH"); use_patch = e ? atoi(e) : 1; }
-    if (use_patch && !ablate && patch_conv_supported(a)) {
-        const long long items = (long long)cdiv(p.M, 256) * (a.Npad / (a.Npad % 128 == 0 ? 128 : 64));
-        if (items >= use_patch * 96) return launch_conv3x3_patch(a, nullptr, s);
-    }
+    // (chosen by layer geometry only, never by batch size: a frame's result must not depend on
+    // what else is in the batch)
+    if (use_patch && patch_conv_supported(a) && a.H * a.W >= use_patch * 400)
+        return launch_conv3x3_patch(a, nullptr, s);
     switch (a.dtype) {
         case TDRN_F32: return launch_dt<float>(p, a.phases, s);
         case TDRN_BF16: return launch_dt<bf16_t>(p, a.phases, s);

@@ -80,6 +80,7 @@ struct tdrn_net {
     bool profile = false;
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_stat;
+    std::vector<int> ev_op;
     tdrn_kernel_stat stats[ST_COUNT];
     int last_batch = 0;
     // independent branches of the tail (TCB laterals, ARM heads) run on side streams; dependencies
@@ -715,6 +716,7 @@ struct tdrn_net {
             for (size_t i = old; i < ev.size(); ++i) TDRN_HIP_TRY(hipEventCreate(&ev[i]));
         }
         ev_stat.clear();
+        ev_op.clear();
         // profiling runs single-stream so that per-kernel durations are not polluted by overlap
         const bool lanes = use_lanes && !profile;
         bool lane_used[kLanes] = {true, false, false, false};
@@ -846,6 +848,7 @@ struct tdrn_net {
             if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) {
                 TDRN_HIP_TRY(hipEventRecord(ev[evi + 1], s));
                 ev_stat.push_back(o.stat);
+                ev_op.push_back((int)oi);
                 evi += 2;
             }
         }
@@ -1000,6 +1003,27 @@ int tdrn_net_profile(tdrn_net *net, int enable)
     if (!net) return TDRN_E_ARG;
     net->profile = enable != 0;
     return TDRN_OK;
+}
+
+int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries)
+{
+    if (!net || !out || max_entries <= 0) return TDRN_E_ARG;
+    int n = 0;
+    for (size_t i = 0; i < net->ev_op.size() && n < max_entries; ++i) {
+        const Op &o = net->ops[net->ev_op[i]];
+        float ms = 0.f;
+        TDRN_HIP_TRY(hipEventSynchronize(net->ev[2 * i + 1]));
+        TDRN_HIP_TRY(hipEventElapsedTime(&ms, net->ev[2 * i], net->ev[2 * i + 1]));
+        tdrn_kernel_stat &k = out[n++];
+        memset(&k, 0, sizeof(k));
+        std::string name = std::string(kStatNames[o.stat]) + ":" + (o.w.empty() ? (o.in >= 0 ? net->tensors[o.in].label : "") : o.w);
+        strncpy(k.name, name.c_str(), sizeof(k.name) - 1);
+        k.launches = 1;
+        k.flops = o.flops * net->last_batch;
+        k.bytes = o.bytes * net->last_batch;
+        k.ms = ms;
+    }
+    return n;
 }
 
 int tdrn_net_kernel_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries)

@@ -165,3 +165,10 @@ class NetEngine(object):
             check(n)
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, flops=arr[i].flops,
                      bytes=arr[i].bytes, ms=arr[i].ms) for i in range(n)]
+
+    def op_stats(self):
+        arr = (KernelStat * 128)()
+        n = self.lib.tdrn_net_op_stats(self.handle, arr, 128)
+        if n < 0:
+            check(n)
+        return [dict(name=arr[i].name.decode(), flops=arr[i].flops, bytes=arr[i].bytes, ms=arr[i].ms) for i in range(n)]
