@@ -52,19 +52,19 @@ def vgg_trunk(sd, x, bn=True, taps=None):
     feats = []
     n_conv = 0
     for v in VGG_CFG:
-        if v == "M":
-            x = F.max_pool2d(x, 2, 2)
-            idx += 1
-        elif v == "C":
-            x = F.max_pool2d(x, 2, 2, ceil_mode=True)
+        if v in ("M", "C"):
+            x = F.max_pool2d(x, 2, 2, ceil_mode=(v == "C"))
+            if taps is not None:
+                taps["pool:" + last] = x
             idx += 1
         else:
             x = _conv(sd, "backbone.%d" % idx, x, padding=1)
             if bn:
                 x = _bn(sd, "backbone.%d" % (idx + 1), x)
             x = F.relu(x)
+            last = "backbone.%d" % idx
             if taps is not None:
-                taps["backbone.%d" % idx] = x
+                taps[last] = x
             idx += 3 if bn else 2
             n_conv += 1
             if n_conv in (10, 13):          # conv4_3, conv5_3

@@ -300,6 +300,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     }
 }
 
+int conv_patch_enabled()
+{
+    static int use_patch = -1;
+    if (use_patch < 0) { const char *e = getenv("TDRN_CONV_PATCH"); use_patch = e ? atoi(e) : 1; }
+    return use_patch;
+}
+
 int conv_n_pad(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : (int)align_up((size_t)cout, 128)); }
 
 template <typename DT, int BM, int BN, int WGM, int WGN, int STAGES>

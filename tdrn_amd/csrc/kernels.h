@@ -30,6 +30,7 @@ struct ConvArgs {
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
 // warp-specialised 3x3/s1/p1 kernel (conv3x3_patch.hip); out_pool = optional fused MaxPool2d(2,2) output
+int conv_patch_enabled();                       // TDRN_CONV_PATCH (default 1)
 int patch_conv_supported(const ConvArgs &a);   // 0 = no, 32/16 = 2-D tiles, -1 = flat tiles
 int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s);
 // rows of the packed weight matrix must be padded to a multiple of this

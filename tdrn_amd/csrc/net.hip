@@ -55,6 +55,7 @@ struct Op {
     double flops = 0, bytes = 0;                           // algorithmic, per sample
     int stat = 0;
     int lane = 0;                                          // HIP stream lane (0 = the caller's stream)
+    int pool_t = -1;                                       // conv: fused MaxPool2d(2,2) output tensor (patch kernel)
 };
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
@@ -197,8 +198,29 @@ struct tdrn_net {
         return o.out;
     }
 
-    int pool(int in, int ceil_mode)
+    // MaxPool2d(2,2) right after a 3x3 conv whose full-resolution output nobody else reads: fused into
+    // the conv's epilogue when the warp-specialised kernel takes the layer with 2-D tiles.
+    bool can_fuse_pool(int in) const
     {
+        if (ops.empty()) return false;
+        const Op &o = ops.back();
+        if (o.kind != OP_CONV || o.out != in || o.out_kind != OUT_TENSOR || o.k != 3 || o.stride != 1 || o.pad != 1 ||
+            o.dil != 1 || o.phases != 1 || o.res >= 0 || o.pool_t >= 0) return false;
+        const Tensor &t = tensors[in];
+        if ((t.H & 1) || (t.W & 1)) return false;
+        return (t.W % 32 == 0 && t.H % 8 == 0) || (t.W % 16 == 0 && t.H % 16 == 0);
+    }
+    int pool(int in, int ceil_mode, bool in_needed_elsewhere = false)
+    {
+        if (!in_needed_elsewhere && can_fuse_pool(in)) {
+            const Tensor ti = tensors[in];
+            const int out = T(ti.C, ti.H / 2, ti.W / 2);
+            label(out, "pool:" + ti.label);
+            ops.back().pool_t = out;
+            tensors[in].label = "";                  // not materialised on the fused path
+            ops.back().bytes += (double)(ti.H / 2) * (ti.W / 2) * ti.Cpad * es - (double)ti.H * ti.W * ti.Cpad * es;
+            return out;
+        }
         const Tensor ti = tensors[in];
         Op o; o.kind = OP_POOL; o.stat = ST_POOL; o.in = in; o.ceil = ceil_mode;
         const int Ho = ceil_mode ? (ti.H + 1) / 2 : ti.H / 2, Wo = ceil_mode ? (ti.W + 1) / 2 : ti.W / 2;
@@ -329,7 +351,7 @@ struct tdrn_net {
         int idx = 0, x = -1, nconv = 0;
         for (int v : cfgv) {
             if (v < 0) {
-                x = pool(x, v == -2);
+                x = pool(x, v == -2, nconv == 10 || nconv == 13);
                 idx += 1;
                 continue;
             }
@@ -342,7 +364,7 @@ struct tdrn_net {
             if (nconv == 10) c43 = x;
             if (nconv == 13) c53 = x;
         }
-        x = pool(x, 0);   // pool5_ds
+        x = pool(x, 0, true);   // pool5_ds (conv5_3 also feeds L2Norm_5_3)
         idx += 1;
         x = conv(x, "backbone." + std::to_string(idx), true, bn ? "backbone." + std::to_string(idx + 1) : "", 1024, 3, 1, 6, 6, 1);
         idx += bn ? 3 : 2;
@@ -499,8 +521,10 @@ struct tdrn_net {
         if (e && atoi(e) <= 1) use_lanes = false;
         tensor_lane.assign(tensors.size(), 0);
         tensor_shared.assign(tensors.size(), 0);
-        for (const Op &o : ops)
+        for (const Op &o : ops) {
             if (o.out >= 0) tensor_lane[o.out] = o.lane;
+            if (o.pool_t >= 0) tensor_lane[o.pool_t] = o.lane;
+        }
         for (const Op &o : ops)
             for (int t : {o.in, o.res, o.off_t})
                 if (t >= 0 && tensor_lane[t] != o.lane) tensor_shared[t] = 1;
@@ -776,6 +800,18 @@ struct tdrn_net {
                         a.o_base = (long long)scale_off[o.scale] * per_prior;
                         a.o_bs = (long long)P * per_prior; a.o_rs = (long long)a.Wo * per; a.o_cs = per;
                     }
+                    if (o.pool_t >= 0) {
+                        const Tensor &tp = tensors[o.pool_t];
+                        if (conv_patch_enabled() && patch_conv_supported(a) > 0) {
+                            a.out = nullptr;                 // only the pooled map leaves the chip
+                            rc = launch_conv3x3_patch(a, tptr(ws, o.pool_t, B), s);
+                        } else {
+                            rc = launch_conv(a, s);
+                            if (rc == TDRN_OK)
+                                rc = launch_maxpool2(a.out, tptr(ws, o.pool_t, B), B, a.Ho, a.Wo, tp.Cpad, 0, cfg.dtype, s);
+                        }
+                        break;
+                    }
                     rc = launch_conv(a, s);
                     break;
                 }
@@ -845,6 +881,7 @@ struct tdrn_net {
             }
             if (rc != TDRN_OK) return rc;
             if (lanes && o.out >= 0 && tensor_shared[o.out]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.out], s));
+            if (lanes && o.pool_t >= 0 && tensor_shared[o.pool_t]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.pool_t], s));
             if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) {
                 TDRN_HIP_TRY(hipEventRecord(ev[evi + 1], s));
                 ev_stat.push_back(o.stat);

@@ -144,7 +144,7 @@ class NetEngine(object):
         for i in range(self.lib.tdrn_net_tensor_count(self.handle)):
             lab, c, h, w = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
             check(self.lib.tdrn_net_tensor_info(self.handle, i, C.byref(lab), C.byref(c), C.byref(h), C.byref(w)))
-            out.append((lab.value.decode(), c.value, h.value, w.value))
+            out.append((lab.value.decode(), c.value, h.value, w.value))   # '' = not materialised (fused away)
         return out
 
     def read_tensor(self, index, batch):
