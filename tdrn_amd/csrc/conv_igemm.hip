@@ -30,6 +30,8 @@ struct ConvParams {
     long long o_bs, o_rs, o_cs, o_base, o_pr, o_pc;
     int n_tiles, Ktot;
     int out_linear;   // out element (m, c) at o_base + m*o_cs + c (plain NHWC tensor): no index decode
+    int splits;       // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to `partial`
+    float *partial;   // [splits][phases][M][Npad] fp32
     int ablate;   // diagnostics only (TDRN_CONV_ABLATE): 1 = skip the K-loop loads, 2 = skip the MFMAs
 };
 
@@ -174,9 +176,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
         }
     };
 
-    const int nk = p.kh * p.kw * (p.Cin / CK);
+    int nk = p.kh * p.kw * (p.Cin / CK);
+    if (p.splits > 1) {
+        // this workgroup's K slice [ks0, ks1): position the (tap, channel) cursor at ks0
+        const int per = (nk + p.splits - 1) / p.splits;
+        const int ks0 = blockIdx.y * per, ks1 = min(nk, ks0 + per);
+        const int cpt = p.Cin / CK;                  // K-steps per tap
+        const int tap0 = ks0 / cpt;
+        tr = tap0 / p.kw;
+        tq = tap0 - tr * p.kw;
+        c0 = (ks0 - tap0 * cpt) * CK;
+        kofs = ks0 * CK;
+        nk = ks1 > ks0 ? ks1 - ks0 : 0;
+    }
     if constexpr (STAGES == 2) {
-        stage(0);
+        if (nk > 0) stage(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int ks = 0; ks < nk; ++ks) {
@@ -219,12 +233,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     }
 
     // ---- epilogue: + bias, transpose through LDS (fp32), residual, ReLU, coalesced store -----
+    const bool partial_out = p.splits > 1;
 #pragma unroll
     for (int ci = 0; ci < WC; ++ci) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cl = wn * (WC * 32) + ci * 32 + 8 * g + 4 * hh;   // local cout of reg 4g
-            const f32x4 bv = *(const f32x4 *)(p.bias + n0 + cl);
+            const f32x4 bv = partial_out ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(p.bias + n0 + cl);
 #pragma unroll
             for (int pi = 0; pi < WP; ++pi) {
                 f32x4 v;
@@ -236,6 +251,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     }
     __syncthreads();
 
+    if (partial_out) {
+        // raw fp32 partial tile -> slab [split][phase][m][Npad]; bias / residual / ReLU happen in the reduce kernel
+        constexpr int CPR = BN / 4;
+        float *slab = p.partial + ((size_t)blockIdx.y * gridDim.z + z) * (size_t)p.M * p.Npad;
+        for (int idx = t; idx < BM * CPR; idx += NT) {
+            const int row = idx / CPR, chn = idx - row * CPR;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            *(f32x4 *)(slab + (size_t)m * p.Npad + n0 + chn * 4) = *(const f32x4 *)(smem + row * CS + chn * 16);
+        }
+        return;
+    }
     if (p.out_f32) {
         // fp32 heads (ARM loc / conf logits): 4 channels per chunk, scalar stores when unaligned
         constexpr int CPR = BN / 4;
@@ -315,7 +342,7 @@ static int launch_cfg(const ConvParams &p, int phases, hipStream_t s)
     const int mt = cdiv(p.M, BM);
     ConvParams q = p;
     q.n_tiles = p.Npad / BN;
-    dim3 grid((unsigned)(mt * q.n_tiles), 1, (unsigned)phases);
+    dim3 grid((unsigned)(mt * q.n_tiles), (unsigned)q.splits, (unsigned)phases);
     hipLaunchKernelGGL((conv_igemm_kernel<DT, BM, BN, WGM, WGN, STAGES>), grid, dim3(64 * WGM * WGN), 0, s, q);
     return hip_status(hipGetLastError());
 }
@@ -335,6 +362,58 @@ template <typename DT> static int launch_dt(const ConvParams &p, int phases, hip
     if (p.Npad % 128 == 0) return launch_cfg<DT, 128, 128, 2, 2, 2>(p, phases, s);
     if (p.Npad % 64 == 0) return launch_cfg<DT, 128, 64, 2, 2, 2>(p, phases, s);
     return launch_cfg<DT, 128, 32, 4, 1, 2>(p, phases, s);
+}
+
+// split-K second pass: out = epilogue(sum_s partial[s]) with the same views / flags as the fused epilogue
+template <typename DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, int phases)
+{
+    constexpr int ES = elem_traits<DT>::bytes;
+    const int C4 = (p.Cout + 3) / 4;
+    const long long total = (long long)phases * p.M * C4;
+    const int HoWo = p.Ho * p.Wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const long long r = i / C4;
+        const int m = (int)(r % p.M), z = (int)(r / p.M);
+        f32x4 v = *(const f32x4 *)(p.bias + c);
+        for (int sidx = 0; sidx < p.splits; ++sidx)
+            v += *(const f32x4 *)(p.partial + (((size_t)sidx * phases + z) * p.M + m) * p.Npad + c);
+        const int b = m / HoWo, rem = m - b * HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const long long eo = p.o_base + (z >> 1) * p.o_pr + (z & 1) * p.o_pc + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c + j >= p.Cout) break;
+            float x = v[j];
+            if (p.res) x += to_f32<DT>(*(const DT *)(p.res + (eo + j) * ES));
+            if (p.relu) x = fmaxf(x, 0.f);
+            if (p.out_f32) ((float *)p.out)[eo + j] = x;
+            else *(DT *)(p.out + (eo + j) * ES) = from_f32<DT>(x);
+        }
+    }
+}
+
+// number of K slices for a small-M problem: fill the chip (~2 workgroups per CU) but keep >= 4 K-steps each
+int conv_splitk_choice(const ConvArgs &a)
+{
+    static int enabled = -1;
+    if (enabled < 0) { const char *e = getenv("TDRN_SPLITK"); enabled = e ? atoi(e) : 1; }
+    if (!enabled) return 1;
+    const int es = dtype_bytes(a.dtype);
+    const int nk = a.kh * a.kw * (a.Cin / (128 / es));
+    const int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
+    const long long blocks = (long long)cdiv(a.B * a.Ho * a.Wo, 128) * (a.Npad / bn) * a.phases;
+    if (conv_patch_enabled() && patch_conv_supported(a) && a.H * a.W >= conv_patch_enabled() * 400) return 1;
+    if (blocks >= 160 || nk < 8) return 1;
+    int s = (int)((384 + blocks - 1) / blocks);
+    if (s > nk / 4) s = nk / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+size_t conv_splitk_bytes(const ConvArgs &a, int splits)
+{
+    return splits > 1 ? (size_t)splits * a.phases * a.B * a.Ho * a.Wo * a.Npad * sizeof(float) : 0;
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t s)
@@ -364,6 +443,8 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     p.out_linear = (!a.out_f32 && a.phases == 1 && a.o_rs == (long long)a.Wo * a.o_cs &&
                     a.o_bs == (long long)a.Ho * a.Wo * a.o_cs) ? 1 : 0;
     p.n_tiles = 0;
+    p.splits = (a.splitk > 1 && a.partial) ? a.splitk : 1;
+    p.partial = (float *)a.partial;
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
@@ -373,14 +454,23 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     if (use_patch < 0) { const char *e = getenv("TDRN_CONV_PATCH"); use_patch = e ? atoi(e) : 1; }
     // (chosen by layer geometry only, never by batch size: a frame's result must not depend on
     // what else is in the batch)
-    if (use_patch && patch_conv_supported(a) && a.H * a.W >= use_patch * 400)
+    if (p.splits == 1 && use_patch && patch_conv_supported(a) && a.H * a.W >= use_patch * 400)
         return launch_conv3x3_patch(a, nullptr, s);
+    int rc = TDRN_E_ARG;
     switch (a.dtype) {
-        case TDRN_F32: return launch_dt<float>(p, a.phases, s);
-        case TDRN_BF16: return launch_dt<bf16_t>(p, a.phases, s);
-        case TDRN_F16: return launch_dt<f16_t>(p, a.phases, s);
+        case TDRN_F32: rc = launch_dt<float>(p, a.phases, s); break;
+        case TDRN_BF16: rc = launch_dt<bf16_t>(p, a.phases, s); break;
+        case TDRN_F16: rc = launch_dt<f16_t>(p, a.phases, s); break;
     }
-    return TDRN_E_ARG;
+    if (rc != TDRN_OK || p.splits == 1) return rc;
+    const long long total = (long long)a.phases * p.M * ((p.Cout + 3) / 4);
+    dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256));
+    switch (a.dtype) {
+        case TDRN_F32: hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, dim3(256), 0, s, p, a.phases); break;
+        case TDRN_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), grid, dim3(256), 0, s, p, a.phases); break;
+        case TDRN_F16: hipLaunchKernelGGL((splitk_reduce_kernel<f16_t>), grid, dim3(256), 0, s, p, a.phases); break;
+    }
+    return hip_status(hipGetLastError());
 }
 
 }  // namespace tdrn

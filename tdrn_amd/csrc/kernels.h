@@ -25,10 +25,14 @@ struct ConvArgs {
     int Ho = 0, Wo = 0, Cout = 0, Npad = 0;
     int kh = 1, kw = 1, stride = 1, pad = 0, dil = 1;
     int relu = 0, out_f32 = 0, phases = 1;
+    int splitk = 1;                 // > 1: K is cut into slices over blockIdx.y (small-M layers); needs `partial`
+    void *partial = nullptr;        // fp32 scratch of conv_splitk_bytes()
     long long o_bs = 0, o_rs = 0, o_cs = 0, o_base = 0, o_pr = 0, o_pc = 0;
     int dtype = TDRN_BF16;
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
+int conv_splitk_choice(const ConvArgs &a);          // 1 = no split
+size_t conv_splitk_bytes(const ConvArgs &a, int splits);
 // warp-specialised 3x3/s1/p1 kernel (conv3x3_patch.hip); out_pool = optional fused MaxPool2d(2,2) output
 int conv_patch_enabled();                       // TDRN_CONV_PATCH (default 1)
 int patch_conv_supported(const ConvArgs &a);   // 0 = no, 32/16 = 2-D tiles, -1 = flat tiles

@@ -56,6 +56,7 @@ struct Op {
     int stat = 0;
     int lane = 0;                                          // HIP stream lane (0 = the caller's stream)
     int pool_t = -1;                                       // conv: fused MaxPool2d(2,2) output tensor (patch kernel)
+    int splitk = 1;                                        // conv: K slices, fixed per layer at plan time
 };
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
@@ -87,6 +88,7 @@ struct tdrn_net {
     // independent branches of the tail (TCB laterals, ARM heads) run on side streams; dependencies
     // between lanes are hipEvents on the producing tensor.  Created lazily at the first forward.
     static constexpr int kLanes = 4;
+    size_t splitk_off[kLanes] = {0, 0, 0, 0};   // per-lane split-K slab region (bytes per sample from workspace start)
     int cur_lane = 0;
     bool use_lanes = true, lanes_ready = false;
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
@@ -517,6 +519,28 @@ struct tdrn_net {
             default: return TDRN_E_UNSUPPORTED;
         }
         if (rc != TDRN_OK) return rc;
+        // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
+        // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
+        {
+            size_t lane_bytes[kLanes] = {0, 0, 0, 0};
+            for (Op &o : ops) {
+                if (o.kind != OP_CONV || o.pool_t >= 0) continue;
+                const Tensor &ti = tensors[o.in];
+                ConvArgs a;
+                a.B = 8; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
+                a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
+                a.phases = o.phases; a.dtype = cfg.dtype; a.out_f32 = o.out_kind != OUT_TENSOR;
+                o.splitk = conv_splitk_choice(a);
+                if (o.splitk > 1) {
+                    const size_t per_sample = align_up((size_t)o.splitk * o.phases * a.Ho * a.Wo * o.Npad * sizeof(float), 256);
+                    if (per_sample > lane_bytes[o.lane]) lane_bytes[o.lane] = per_sample;
+                }
+            }
+            for (int l = 0; l < kLanes; ++l) {
+                splitk_off[l] = ws_per_sample;
+                ws_per_sample += lane_bytes[l];
+            }
+        }
         const char *e = getenv("TDRN_STREAMS");
         if (e && atoi(e) <= 1) use_lanes = false;
         tensor_lane.assign(tensors.size(), 0);
@@ -799,6 +823,10 @@ struct tdrn_net {
                         a.out = base; a.out_f32 = 1;
                         a.o_base = (long long)scale_off[o.scale] * per_prior;
                         a.o_bs = (long long)P * per_prior; a.o_rs = (long long)a.Wo * per; a.o_cs = per;
+                    }
+                    if (o.splitk > 1) {
+                        a.splitk = o.splitk;
+                        a.partial = (char *)ws + splitk_off[o.lane] * (size_t)B;
                     }
                     if (o.pool_t >= 0) {
                         const Tensor &tp = tensors[o.pool_t];
