@@ -153,7 +153,8 @@ typedef struct {
     int deform;       /* ssd4scale_*: deformable ARM heads (df_group = 8), TRN temporal net */
     int test_phase;   /* 1: softmax on conf (phase == 'test'); 0: raw logits                */
     int dtype;        /* tdrn_dtype of the dense path                                       */
-    int reserved[6];
+    int use_refine;   /* refinedet_vgg: ARM loc heads present (4-tuple output)               */
+    int reserved[5];
 } tdrn_net_config;
 
 typedef struct tdrn_net tdrn_net;

@@ -208,36 +208,96 @@ def drn_mobilenet_forward(sd, x, num_classes=21, multihead=False, phase="test", 
         return arm_loc, None, odm_loc, conf
 
 
+def _ssd4scale_heads(sd, srcs, x, num_classes, phase, deform_on, ref_loc, offset_list, ret_loc, ret_off):
+    """Shared by model/ssd4scale_mobile.py:86-140 and model/ssd4scale_vgg.py:71-135 (df_group = 8)."""
+    offs = None
+    if deform_on:
+        offs = offset_list or [_conv(sd, "offset.%d" % s, torch.as_tensor(rl)) for s, rl in enumerate(ref_loc)]
+    locs, confs, raw = [], [], []
+    for s, src in enumerate(srcs):
+        if deform_on:
+            l = deform(src, offs[s], sd["arm_loc.%d.weight" % s], 1, 8)
+            cf = deform(src, offs[s], sd["arm_conf.%d.weight" % s], 1, 8)
+        else:
+            l = _conv(sd, "arm_loc.%d" % s, src, padding=1)
+            cf = _conv(sd, "arm_conf.%d" % s, src, padding=1)
+            raw.append(l)
+        locs.append(l.permute(0, 2, 3, 1).contiguous())
+        confs.append(cf.permute(0, 2, 3, 1).contiguous())
+    B = x.size(0)
+    loc = torch.cat([o.view(B, -1) for o in locs], 1).view(B, -1, 4)
+    conf = torch.cat([o.view(B, -1) for o in confs], 1)
+    conf = F.softmax(conf.view(-1, num_classes), dim=1) if phase == "test" else conf.view(B, -1, num_classes)
+    out = [loc, conf]
+    if ret_loc:
+        out.append(raw)
+    if ret_off:
+        out.append(offs)
+    return tuple(out)
+
+
+def _vgg_sources(sd, x, bn):
+    c43, c53, fc7 = vgg_trunk(sd, x, bn)
+    e = _conv(sd, "extras.0", fc7)
+    if bn:
+        e = F.relu(_bn(sd, "extras.1", e))
+        e = F.relu(_bn(sd, "extras.4", _conv(sd, "extras.3", e, stride=2, padding=1)))
+    else:
+        e = F.relu(e)
+        e = F.relu(_conv(sd, "extras.2", e, stride=2, padding=1))
+    return [_l2norm(sd, "L2Norm_4_3", c43), _l2norm(sd, "L2Norm_5_3", c53), fc7, e]
+
+
+def ssd4scale_vgg_forward(sd, x, num_classes=21, phase="test", bn=True, deform_on=False, ref_loc=None,
+                          offset_list=None, ret_loc=False, ret_off=False):
+    """model/ssd4scale_vgg.py:71-135."""
+    x = torch.as_tensor(x)
+    with torch.no_grad():
+        return _ssd4scale_heads(sd, _vgg_sources(sd, x, bn), x, num_classes, phase, deform_on, ref_loc,
+                                offset_list, ret_loc, ret_off)
+
+
+def refinedet_vgg_forward(sd, x, num_classes=21, use_refine=False, bn=False, multihead=False, phase="test"):
+    """model/refinedet_vgg.py:112-219 (plain conv ODM heads; multihead = 3x3 + 5x5 summed)."""
+    x = torch.as_tensor(x)
+    with torch.no_grad():
+        srcs = _vgg_sources(sd, x, bn)
+        B = x.size(0)
+        arm_loc = None
+        if use_refine:
+            arm_loc = torch.cat([_conv(sd, "arm_loc.%d" % s, a, padding=1).permute(0, 2, 3, 1).contiguous().view(B, -1)
+                                 for s, a in enumerate(srcs)], 1).view(B, -1, 4)
+        xx = F.relu(_conv(sd, "last_layer_trans.0", srcs[3], padding=1))
+        xx = _conv(sd, "last_layer_trans.3", _conv(sd, "last_layer_trans.2", xx, padding=1), padding=1)
+        odm = [xx]
+        trans = [_conv(sd, "trans_layers.%d.2" % s, F.relu(_conv(sd, "trans_layers.%d.0" % s, srcs[s], padding=1)), padding=1)
+                 for s in range(3)]
+        trans.reverse()
+        for i, t in enumerate(trans):
+            u = F.conv_transpose2d(xx, _t(sd, "up_layers.%d.weight" % i), _t(sd, "up_layers.%d.bias" % i), stride=2)
+            xx = F.relu(_conv(sd, "latent_layers.%d" % i, F.relu(u + t), padding=1))
+            odm.append(xx)
+        odm.reverse()
+        locs, confs = [], []
+        for s, ob in enumerate(odm):
+            l = _conv(sd, "odm_loc.%d" % s, ob, padding=1)
+            c = _conv(sd, "odm_conf.%d" % s, ob, padding=1)
+            if multihead:
+                l = l + _conv(sd, "odm_loc_2.%d" % s, ob, padding=2)
+                c = c + _conv(sd, "odm_conf_2.%d" % s, ob, padding=2)
+            locs.append(l.permute(0, 2, 3, 1).contiguous().view(B, -1))
+            confs.append(c.permute(0, 2, 3, 1).contiguous().view(B, -1))
+        odm_loc = torch.cat(locs, 1).view(B, -1, 4)
+        conf = torch.cat(confs, 1)
+        conf = F.softmax(conf.view(-1, num_classes), dim=1) if phase == "test" else conf.view(B, -1, num_classes)
+        return (arm_loc, None, odm_loc, conf) if use_refine else (odm_loc, conf)
+
+
 def ssd4scale_mobile_forward(sd, x, num_classes=21, phase="test", deform_on=False, ref_loc=None,
                              offset_list=None, ret_loc=False, ret_off=False):
     """model/ssd4scale_mobile.py:86-140 (df_group = 8 when deform)."""
     x = torch.as_tensor(x)
     with torch.no_grad():
-        offs = None
-        if deform_on:
-            offs = offset_list or [_conv(sd, "offset.%d" % s, torch.as_tensor(rl))
-                                   for s, rl in enumerate(ref_loc)]
         a, b, c, d = mobilenet_trunk(sd, x)
         srcs = [_l2norm(sd, "L2Norm_4_3", a), _l2norm(sd, "L2Norm_5_3", b), c, d]
-        locs, confs, raw = [], [], []
-        for s, src in enumerate(srcs):
-            if deform_on:
-                l = deform(src, offs[s], sd["arm_loc.%d.weight" % s], 1, 8)
-                cf = deform(src, offs[s], sd["arm_conf.%d.weight" % s], 1, 8)
-            else:
-                l = _conv(sd, "arm_loc.%d" % s, src, padding=1)
-                cf = _conv(sd, "arm_conf.%d" % s, src, padding=1)
-                raw.append(l)
-            locs.append(l.permute(0, 2, 3, 1).contiguous())
-            confs.append(cf.permute(0, 2, 3, 1).contiguous())
-        B = x.size(0)
-        loc = torch.cat([o.view(B, -1) for o in locs], 1).view(B, -1, 4)
-        conf = torch.cat([o.view(B, -1) for o in confs], 1)
-        conf = F.softmax(conf.view(-1, num_classes), dim=1) if phase == "test" \
-            else conf.view(B, -1, num_classes)
-        out = [loc, conf]
-        if ret_loc:
-            out.append(raw)
-        if ret_off:
-            out.append(offs)
-        return tuple(out)
+        return _ssd4scale_heads(sd, srcs, x, num_classes, phase, deform_on, ref_loc, offset_list, ret_loc, ret_off)

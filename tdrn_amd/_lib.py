@@ -24,7 +24,7 @@ class NetConfig(C.Structure):
     _fields_ = [("model", C.c_int), ("size", C.c_int), ("num_classes", C.c_int),
                 ("c7_channel", C.c_int), ("def_groups", C.c_int), ("bn", C.c_int),
                 ("multihead", C.c_int), ("deform", C.c_int), ("test_phase", C.c_int),
-                ("dtype", C.c_int), ("reserved", C.c_int * 6)]
+                ("dtype", C.c_int), ("use_refine", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class NetIO(C.Structure):

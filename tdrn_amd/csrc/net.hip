@@ -427,15 +427,55 @@ struct tdrn_net {
         src[0] = l2norm(c43, "L2Norm_4_3");
         src[1] = l2norm(c53, "L2Norm_5_3");
         src[2] = fc7;
-        if (cfg.bn) {
-            const int e = conv(fc7, "extras.0", true, "extras.1", 256, 1, 1, 0, 1, 1);
-            src[3] = conv(e, "extras.3", true, "extras.4", 512, 3, 2, 1, 1, 1);
-        } else {
-            const int e = conv(fc7, "extras.0", true, "", 256, 1, 1, 0, 1, 1);
-            src[3] = conv(e, "extras.2", true, "", 512, 3, 2, 1, 1, 1);
-        }
+        src[3] = vgg_extras(fc7);
         tcb(src, true, odm);
         drn_heads(src, odm, true);
+        return TDRN_OK;
+    }
+
+    // extras of the VGG variants (dualrefinedet_vggbn.py:36-45, refinedet_vgg.py:47-56, ssd4scale_vgg.py:25-34)
+    int vgg_extras(int fc7)
+    {
+        if (cfg.bn) {
+            const int e = conv(fc7, "extras.0", true, "extras.1", 256, 1, 1, 0, 1, 1);
+            return conv(e, "extras.3", true, "extras.4", 512, 3, 2, 1, 1, 1);
+        }
+        const int e = conv(fc7, "extras.0", true, "", 256, 1, 1, 0, 1, 1);
+        return conv(e, "extras.2", true, "", 512, 3, 2, 1, 1, 1);
+    }
+
+    // RefineDet-VGG: same trunk / TCB, plain (non-deformable) ODM heads (model/refinedet_vgg.py:27-219).
+    // multihead sums a 3x3 and a 5x5 conv of the same input (:179-182): packed as ONE 5x5 conv whose
+    // centre taps carry the 3x3 weights (biases added).
+    int build_refinedet_vgg()
+    {
+        const int S = cfg.size;
+        set_pyramid(S / 8);
+        int c43, c53, fc7;
+        vgg_trunk(S, cfg.bn != 0, cfg.c7_channel, c43, c53, fc7);
+        int src[4], odm[4];
+        src[0] = l2norm(c43, "L2Norm_4_3");
+        src[1] = l2norm(c53, "L2Norm_5_3");
+        src[2] = fc7;
+        src[3] = vgg_extras(fc7);
+        if (cfg.use_refine) {
+            cur_lane = 3;
+            for (int s = 0; s < 4; ++s) conv(src[s], "arm_loc." + std::to_string(s), true, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
+            cur_lane = 0;
+        }
+        tcb(src, true, odm);
+        const int nc3 = 3 * cfg.num_classes;
+        for (int s = 0; s < 4; ++s) {
+            const std::string ss = std::to_string(s);
+            if (cfg.multihead) {
+                conv(odm[s], "odm_loc_2." + ss, true, "", 12, 5, 1, 2, 1, 0, -1, OUT_ODM_LOC, s, "odm_loc." + ss, 3);
+                conv(odm[s], "odm_conf_2." + ss, true, "", nc3, 5, 1, 2, 1, 0, -1, OUT_CONF, s, "odm_conf." + ss, 3);
+            } else {
+                conv(odm[s], "odm_loc." + ss, true, "", 12, 3, 1, 1, 1, 0, -1, OUT_ODM_LOC, s);
+                conv(odm[s], "odm_conf." + ss, true, "", nc3, 3, 1, 1, 1, 0, -1, OUT_CONF, s);
+            }
+        }
+        if (cfg.test_phase) softmax_op();
         return TDRN_OK;
     }
 
@@ -484,7 +524,12 @@ struct tdrn_net {
             src[2] = raw[2];
             src[3] = raw[3];
         } else {
-            return TDRN_E_UNSUPPORTED;
+            int c43, c53, fc7;
+            vgg_trunk(cfg.size, cfg.bn != 0, cfg.c7_channel, c43, c53, fc7);
+            src[0] = l2norm(c43, "L2Norm_4_3");
+            src[1] = l2norm(c53, "L2Norm_5_3");
+            src[2] = fc7;
+            src[3] = vgg_extras(fc7);
         }
         const int nc3 = 3 * cfg.num_classes;
         for (int s = 0; s < 4; ++s) {
@@ -516,6 +561,8 @@ struct tdrn_net {
             case TDRN_DRN_VGGBN: rc = build_drn_vgg(); break;
             case TDRN_DRN_MOBILENET: rc = build_drn_mobilenet(); break;
             case TDRN_SSD4SCALE_MOBILE: rc = build_ssd4scale(true); break;
+            case TDRN_SSD4SCALE_VGG: rc = build_ssd4scale(false); break;
+            case TDRN_REFINEDET_VGG: rc = build_refinedet_vgg(); break;
             default: return TDRN_E_UNSUPPORTED;
         }
         if (rc != TDRN_OK) return rc;
@@ -751,9 +798,11 @@ struct tdrn_net {
         if (!blob || !ws || !io || !io->x || io->batch <= 0) return TDRN_E_ARG;
         const int B = io->batch;
         if (ws_bytes < ws_per_sample * (size_t)B) return TDRN_E_WORKSPACE;
-        if (!io->arm_loc || !io->conf) return TDRN_E_ARG;
+        if (!io->conf) return TDRN_E_ARG;
         const bool is_drn = cfg.model == TDRN_DRN_VGGBN || cfg.model == TDRN_DRN_MOBILENET || cfg.model == TDRN_REFINEDET_VGG;
+        const bool has_arm = cfg.model != TDRN_REFINEDET_VGG || cfg.use_refine;
         if (is_drn && !io->odm_loc) return TDRN_E_ARG;
+        if (has_arm && !io->arm_loc) return TDRN_E_ARG;
         const char *wb = (const char *)blob;
         const int C = cfg.num_classes;
         last_batch = B;

@@ -14,13 +14,13 @@ from ._lib import NetConfig, NetIO, KernelStat, check, ptr
 
 class NetEngine(object):
     def __init__(self, model, size, num_classes=21, c7_channel=1024, def_groups=1, bn=True,
-                 multihead=False, deform=False, test_phase=True, dtype="fp32"):
+                 multihead=False, deform=False, test_phase=True, dtype="fp32", use_refine=False):
         self.lib = _lib.lib()
         self.dtype_name = dtype
         cfg = NetConfig(model=model, size=size, num_classes=num_classes, c7_channel=c7_channel,
                         def_groups=def_groups, bn=int(bool(bn)), multihead=int(bool(multihead)),
                         deform=int(bool(deform)), test_phase=int(bool(test_phase)),
-                        dtype=_lib.DTYPES[dtype])
+                        dtype=_lib.DTYPES[dtype], use_refine=int(bool(use_refine)))
         self.cfg = cfg
         h = C.c_void_p()
         check(self.lib.tdrn_net_create(C.byref(cfg), C.byref(h)), "tdrn_net_create")
@@ -102,7 +102,8 @@ class NetEngine(object):
         ssd = self.cfg.model in (_lib.SSD4SCALE_MOBILE, _lib.SSD4SCALE_VGG)
         o = out or {}
         arm_loc = o.get("arm_loc")
-        if arm_loc is None:
+        has_arm = not (self.cfg.model == _lib.REFINEDET_VGG and not self.cfg.use_refine)
+        if arm_loc is None and has_arm:
             arm_loc = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
         odm_loc = None
         if not ssd:
@@ -115,7 +116,7 @@ class NetEngine(object):
         io = NetIO()
         io.x = x.data_ptr()
         io.batch = B
-        io.arm_loc = arm_loc.data_ptr()
+        io.arm_loc = arm_loc.data_ptr() if arm_loc is not None else None
         io.odm_loc = odm_loc.data_ptr() if odm_loc is not None else None
         io.conf = conf.data_ptr()
         offsets, loc_maps, keep = None, None, [x]

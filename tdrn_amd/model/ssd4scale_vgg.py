@@ -1,0 +1,63 @@
+"""4-scale SSD on VGG16: drop-in for model/ssd4scale_vgg.py (SSD4Scale :8-68, forward :71-135,
+build_net :146-151) -- the static (deform=False) and temporal (deform=True, 8 deformable groups)
+nets the TRN drivers build (train_trn.py:122-124, evaluate_trn.py:541-543, test_video_trn.py:54-56)."""
+import torch.nn as nn
+
+from .. import _lib
+from ..layers.modules.l2norm import L2Norm
+from ._base import EngineModule
+from .networks import ConvOffset2d, vgg, vgg_base
+from .ssd4scale_mobile import _OffsetList
+
+
+class SSD4Scale(EngineModule):
+    def __init__(self, size, num_classes=21, phase='train', c7_channel=1024, bn=True, deform=False):
+        super(SSD4Scale, self).__init__()
+        self.num_classes, self.size, self.phase, self.bn, self.deform = num_classes, size, phase, bn, deform
+        nb = 3
+        self.backbone = nn.ModuleList(vgg(vgg_base['320'], 3, batch_norm=bn, pool5_ds=True, c7_channel=c7_channel))
+        self.L2Norm_4_3 = L2Norm(512, 10)
+        self.L2Norm_5_3 = L2Norm(512, 8)
+        if bn:
+            self.extras = nn.Sequential(nn.Conv2d(c7_channel, 256, 1), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+                                        nn.Conv2d(256, 512, 3, 2, 1), nn.BatchNorm2d(512), nn.ReLU(inplace=True))
+        else:
+            self.extras = nn.Sequential(nn.Conv2d(c7_channel, 256, 1), nn.ReLU(inplace=True),
+                                        nn.Conv2d(256, 512, 3, 2, 1), nn.ReLU(inplace=True))
+        chans = [512, 512, c7_channel, 512]
+        if deform:
+            g = 8
+            self.offset = nn.ModuleList([nn.Conv2d(nb * 4, g * 18, 1) for _ in range(4)])
+            mk = lambda cout: nn.ModuleList([ConvOffset2d(c, cout, 3, 1, 1, num_deformable_groups=g) for c in chans])
+        else:
+            mk = lambda cout: nn.ModuleList([nn.Conv2d(c, cout, 3, 1, 1) for c in chans])
+        self.arm_loc, self.arm_conf = mk(nb * 4), mk(nb * num_classes)
+        if phase == 'test':
+            self.softmax = nn.Softmax(dim=1)
+        self._engine_init(model=_lib.SSD4SCALE_VGG, size=size, num_classes=num_classes, c7_channel=c7_channel, bn=bn,
+                          deform=deform, test_phase=(phase == 'test'))
+
+    def forward(self, x, ref_loc=list(), offset_list=list(), ret_loc=False, ret_off=False):
+        if self.deform and not ref_loc:
+            ref_loc = getattr(offset_list, "ref_loc", None)
+            if ref_loc is None:
+                raise ValueError("deform=True needs ref_loc (or an offset_list returned by this net)")
+        r = self.engine(x.device).forward(x, want_offsets=bool(ret_off and self.deform),
+                                          ref_loc=ref_loc if self.deform else None,
+                                          want_loc_maps=bool(ret_loc and not self.deform))
+        conf = r["conf"] if self.phase == 'test' else r["conf"].view(x.size(0), -1, self.num_classes)
+        out = [r["arm_loc"], conf]
+        if ret_loc:
+            out.append(r["loc_maps"])
+        if ret_off:
+            offs = _OffsetList(r["offsets"] or [])
+            offs.ref_loc = list(ref_loc)
+            out.append(offs)
+        return tuple(out)
+
+
+def build_net(phase, size=320, num_classes=21, c7_channel=1024, bn=False, deform=False):
+    if size not in [320, 512]:
+        print("Error: Sorry only SSD320 and SSD512 is supported currently!")
+        return
+    return SSD4Scale(size, num_classes=num_classes, phase=phase, c7_channel=c7_channel, bn=bn, deform=deform)

@@ -122,6 +122,52 @@ def main():
             detect=det.numpy())
         print(tag, "arm|odm mean abs", float(arm_loc.abs().mean()), float(odm_loc.abs().mean()),
               "conf max", float(conf.max()), "dets", int((det[..., 0] > 0).sum()))
+    extra_models(ref, torch)
+
+
+def extra_models(ref, torch):
+    """refinedet_vgg / ssd4scale_vgg / ssd4scale_mobile: the reference's own forwards on CPU (only the
+    deform=True temporal nets need the patched deformable op)."""
+    import importlib
+
+    def build(modname, args):
+        mod = importlib.import_module("model." + modname)
+        net = mod.build_net("test", *args)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        return net, shapes
+
+    def load(net, shapes, seed):
+        sd = synth.synth_state_dict(shapes, seed)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return net.eval()
+
+    x = torch.from_numpy(synth.synth_frames(1, 320, 21))
+    out = {}
+    # refinedet_vgg: use_refine + bn + multihead, and the plain 2-output variant
+    net, shapes = build("refinedet_vgg", (320, 21, True, 1024, True, True))
+    with torch.no_grad():
+        arm, _, odm, conf = load(net, shapes, 0)(x)
+    out.update(rd_keys=np.asarray(list(shapes)), rd_arm=arm.numpy()[:, ::SUB], rd_odm=odm.numpy()[:, ::SUB],
+               rd_conf=conf.numpy().reshape(1, -1, 21)[:, ::SUB])
+    net, shapes = build("refinedet_vgg", (320, 21, False, 1024, False, False))
+    with torch.no_grad():
+        odm, conf = load(net, shapes, 0)(x)
+    out.update(rd0_keys=np.asarray(list(shapes)), rd0_odm=odm.numpy()[:, ::SUB], rd0_conf=conf.numpy().reshape(1, -1, 21)[:, ::SUB])
+    # TRN protocol (evaluate_trn.py:438-467): static net -> loc maps -> temporal net
+    for tag, modname in (("sv", "ssd4scale_vgg"), ("sm", "ssd4scale_mobile")):
+        a_static = (320, 21, 1024, True, False) if modname == "ssd4scale_vgg" else (320, 21, 1024, False)
+        a_temp = (320, 21, 1024, True, True) if modname == "ssd4scale_vgg" else (320, 21, 1024, True)
+        snet, sshapes = build(modname, a_static)
+        tnet, tshapes = build(modname, a_temp)
+        with torch.no_grad():
+            loc, conf, maps = load(snet, sshapes, 0)(x, ret_loc=True)
+            tloc, tconf, offs = load(tnet, tshapes, 1)(x, ref_loc=maps, ret_off=True)
+        out.update({tag + "_keys": np.asarray(list(sshapes)), tag + "_tkeys": np.asarray(list(tshapes)),
+                    tag + "_loc": loc.numpy()[:, ::SUB], tag + "_conf": conf.numpy().reshape(1, -1, 21)[:, ::SUB],
+                    tag + "_map3": maps[3].numpy(), tag + "_tloc": tloc.numpy()[:, ::SUB],
+                    tag + "_tconf": tconf.numpy().reshape(1, -1, 21)[:, ::SUB], tag + "_off3": offs[3].numpy()})
+        print(tag, float(loc.abs().mean()), float(tloc.abs().mean()), float(conf.max()))
+    np.savez_compressed(os.path.join(HERE, "other_models.npz"), sub=SUB, **out)
 
 
 if __name__ == "__main__":

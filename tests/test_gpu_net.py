@@ -181,3 +181,84 @@ def test_state_dict_roundtrip_and_missing_num_batches_tracked():
     assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
     with pytest.raises(ValueError):
         net(x[:, :, :300, :300])
+
+
+def test_refinedet_vgg_matches_oracle_and_reference(golden_dir):
+    """model/refinedet_vgg.py (config #5 names it): 4-tuple with use_refine (+bn +multihead: the 3x3+5x5 heads
+    are packed as one merged 5x5 conv) and the plain 2-tuple variant, vs the reference's own CPU forward."""
+    g = np.load(os.path.join(golden_dir, "other_models.npz"))
+    sub = int(g["sub"])
+    x = synth.synth_frames(1, 320, 21)
+    net, sd = _build("refinedet_vgg", (320, 21, True, 1024, True, True))
+    arm, none, odm, conf = net(torch.from_numpy(x).to(DEV))
+    assert none is None
+    np.testing.assert_allclose(arm.cpu().numpy()[:, ::sub], g["rd_arm"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(odm.cpu().numpy()[:, ::sub], g["rd_odm"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["rd_conf"], atol=1e-3, rtol=0)
+    r = net_ref.refinedet_vgg_forward(sd, x, 21, True, True, True)
+    np.testing.assert_allclose(odm.cpu().numpy(), r[2].numpy(), atol=1e-3, rtol=0)
+    net, sd = _build("refinedet_vgg", (320, 21, False, 1024, False, False))
+    out = net(torch.from_numpy(x).to(DEV))
+    assert len(out) == 2
+    np.testing.assert_allclose(out[0].cpu().numpy()[:, ::sub], g["rd0_odm"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(out[1].cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["rd0_conf"], atol=1e-3, rtol=0)
+
+
+def test_ssd4scale_vgg_trn_protocol_matches_reference(golden_dir):
+    """The nets the TRN drivers actually build (evaluate_trn.py:541-543): static -> loc maps -> temporal."""
+    g = np.load(os.path.join(golden_dir, "other_models.npz"))
+    sub = int(g["sub"])
+    xs = torch.from_numpy(synth.synth_frames(1, 320, 21)).to(DEV)
+    stat, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, False), seed=0)
+    temp, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, True), seed=1)
+    loc, conf, maps = stat(xs, ret_loc=True)
+    np.testing.assert_allclose(loc.cpu().numpy()[:, ::sub], g["sv_loc"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["sv_conf"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(maps[3].cpu().numpy(), g["sv_map3"], atol=1e-3, rtol=0)
+    tloc, tconf, offs = temp(xs, ref_loc=maps, ret_off=True)
+    np.testing.assert_allclose(offs[3].cpu().numpy(), g["sv_off3"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(tloc.cpu().numpy()[:, ::sub], g["sv_tloc"], atol=2e-3, rtol=0)
+    np.testing.assert_allclose(tconf.cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["sv_tconf"], atol=1e-3, rtol=0)
+    # clip of 4 frames at interval 4 (config #5): key frame once, cached offsets afterwards
+    clip = torch.from_numpy(synth.synth_frames(4, 320, 22)).to(DEV)
+    s_out = stat(clip[:1], ret_loc=True)
+    first = temp(clip[:1], ref_loc=s_out[2], ret_off=True)
+    for f in range(1, 4):
+        o = temp(clip[f:f + 1], offset_list=first[2])
+        assert o[0].shape == (1, 6375, 4) and torch.isfinite(o[1]).all()
+
+
+def test_ssd4scale_mobile_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "other_models.npz"))
+    sub = int(g["sub"])
+    xs = torch.from_numpy(synth.synth_frames(1, 320, 21)).to(DEV)
+    stat, _ = _build("ssd4scale_mobile", (320, 21, 1024, False), seed=0)
+    temp, _ = _build("ssd4scale_mobile", (320, 21, 1024, True), seed=1)
+    loc, conf, maps = stat(xs, ret_loc=True)
+    np.testing.assert_allclose(loc.cpu().numpy()[:, ::sub], g["sm_loc"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["sm_conf"], atol=1e-3, rtol=0)
+    tloc, tconf, offs = temp(xs, ref_loc=maps, ret_off=True)
+    np.testing.assert_allclose(tloc.cpu().numpy()[:, ::sub], g["sm_tloc"], atol=2e-3, rtol=0)
+    np.testing.assert_allclose(tconf.cpu().numpy().reshape(1, -1, 21)[:, ::sub], g["sm_tconf"], atol=1e-3, rtol=0)
+
+
+def test_drn_vggbn_512_fp32_and_fp16():
+    """BASELINE config #3 geometry: 512x512, P = 16320, deformable path on; fp32 vs the oracle, fp16 drift."""
+    net, sd = _build("dualrefinedet_vggbn", (512, 21, 1024, 1, True, True))
+    x = synth.synth_frames(1, 512, seed=31)
+    r_arm, r_off, r_odm, r_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, True)
+    arm, offs, odm, conf = net(torch.from_numpy(x).to(DEV))
+    assert arm.shape == (1, 16320, 4) and conf.shape == (16320, 21)
+    assert [tuple(o.shape) for o in offs] == [(1, 18, f, f) for f in (64, 32, 16, 8)]
+    np.testing.assert_allclose(arm.cpu().numpy(), r_arm.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(odm.cpu().numpy(), r_odm.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(conf.cpu().numpy(), r_conf.numpy(), atol=1e-3, rtol=0)
+    pri = PriorBox(mb_cfg["VOC_512_RefineDet"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45).forward(odm, conf, pri, arm_loc_data=arm).cpu().numpy()   # default scale [320]*4
+    mine = orc.detect(odm.cpu().numpy(), conf.cpu().numpy(), pri.cpu().numpy(), arm.cpu().numpy(), (320,) * 4)
+    assert np.array_equal(det[..., 0], mine[..., 0])
+    net.half()
+    a16, _, o16, c16 = net(torch.from_numpy(synth.synth_frames(2, 512, seed=31)).to(DEV))
+    e = (o16[:1].cpu() - r_odm).abs().flatten()
+    assert float(e.mean()) < 0.006 and float(torch.quantile(e[::7], 0.999)) < 0.06
+    assert float((c16[:16320].cpu() - r_conf).abs().mean()) < 6e-4

@@ -175,3 +175,47 @@ def _drn_vggbn_shapes(multihead, c7=1024, nc=21):
     from tdrn_amd.model.dualrefinedet_vggbn import build_net
     net = build_net("test", 320, nc, c7, 1, True, multihead)
     return {k: tuple(v.shape) for k, v in net.state_dict().items()}
+
+
+def _shapes(modname, args):
+    import importlib
+    net = importlib.import_module("tdrn_amd.model." + modname).build_net("test", *args)
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}
+
+
+def test_other_model_restatements_match_reference(golden_dir):
+    """refinedet_vgg (the reference's own CPU forward, no patched op at all), ssd4scale_vgg / _mobile static
+    and temporal (TRN) nets: oracle/net_ref.py vs tests/golden/other_models.npz."""
+    g = _g(golden_dir, "other_models.npz")
+    sub = int(g["sub"])
+    x = synth.synth_frames(1, 320, 21)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    tol = dict(rtol=1e-4, atol=5e-5)
+
+    sh = _shapes("refinedet_vgg", (320, 21, True, 1024, True, True))
+    assert sorted(sh) == sorted(str(k) for k in g["rd_keys"])
+    arm, _, odm, conf = net_ref.refinedet_vgg_forward(synth.synth_state_dict(sh, 0), x, 21, True, True, True)
+    np.testing.assert_allclose(arm.numpy()[:, ::sub], g["rd_arm"], **tol)
+    np.testing.assert_allclose(odm.numpy()[:, ::sub], g["rd_odm"], **tol)
+    np.testing.assert_allclose(conf.numpy().reshape(1, -1, 21)[:, ::sub], g["rd_conf"], **tol)
+    sh = _shapes("refinedet_vgg", (320, 21, False, 1024, False, False))
+    assert sorted(sh) == sorted(str(k) for k in g["rd0_keys"])
+    odm, conf = net_ref.refinedet_vgg_forward(synth.synth_state_dict(sh, 0), x, 21, False, False, False)
+    np.testing.assert_allclose(odm.numpy()[:, ::sub], g["rd0_odm"], **tol)
+    np.testing.assert_allclose(conf.numpy().reshape(1, -1, 21)[:, ::sub], g["rd0_conf"], **tol)
+
+    for tag, modname, a_s, a_t, fwd in (
+            ("sv", "ssd4scale_vgg", (320, 21, 1024, True, False), (320, 21, 1024, True, True),
+             lambda sd, **kw: net_ref.ssd4scale_vgg_forward(sd, x, 21, "test", True, **kw)),
+            ("sm", "ssd4scale_mobile", (320, 21, 1024, False), (320, 21, 1024, True),
+             lambda sd, **kw: net_ref.ssd4scale_mobile_forward(sd, x, 21, "test", **kw))):
+        ss, ts = _shapes(modname, a_s), _shapes(modname, a_t)
+        assert sorted(ss) == sorted(str(k) for k in g[tag + "_keys"]) and sorted(ts) == sorted(str(k) for k in g[tag + "_tkeys"])
+        loc, conf, maps = fwd(synth.synth_state_dict(ss, 0), deform_on=False, ret_loc=True)
+        np.testing.assert_allclose(loc.numpy()[:, ::sub], g[tag + "_loc"], **tol)
+        np.testing.assert_allclose(conf.numpy().reshape(1, -1, 21)[:, ::sub], g[tag + "_conf"], **tol)
+        np.testing.assert_allclose(maps[3].numpy(), g[tag + "_map3"], **tol)
+        tloc, tconf, offs = fwd(synth.synth_state_dict(ts, 1), deform_on=True, ref_loc=maps, ret_off=True)
+        np.testing.assert_allclose(tloc.numpy()[:, ::sub], g[tag + "_tloc"], **tol)
+        np.testing.assert_allclose(tconf.numpy().reshape(1, -1, 21)[:, ::sub], g[tag + "_tconf"], **tol)
+        np.testing.assert_allclose(offs[3].numpy(), g[tag + "_off3"], **tol)
