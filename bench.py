@@ -30,6 +30,19 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X_MICROAR
 GFLOP_PER_FRAME = {320: 77.466, 512: 198.314}                   # BASELINE.md section 2 (multihead)
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streams + WRITE_SIZE, both x1024), or None
+    when no pass exists for this exact workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        e = d.get("%s|%d|%s|%d" % (kernel, args.size, args.dtype, args.batch))
+        return e["hbm_bytes_per_launch"] if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(size, frames=2):
     """Oracle forward + Detect on `frames` frames; returns the cpu_baseline object."""
     import torch
@@ -138,13 +151,13 @@ def main():
             tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
             print("%-44s %8.1f us %8.1f GF %7.1f TF/s %7.2f GB" % (o["name"], o["ms"] * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
     eng.set_profile(False)
-    conv = [s for s in stats if s["name"] == "conv_igemm_mfma"][0]
+    conv = max(stats, key=lambda s: s["ms"])                 # the dominant kernel of the step
     peak = PEAK_TFLOPS[args.dtype]
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_mfma", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                "launches_per_step": conv["launches"], "gflop_per_step": round(conv["flops"] / 1e9, 2),
-                "ms_per_step": round(conv["ms"], 4)}
+    roofline = {"bound": "mfma", "kernel": conv["name"], "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(conv["name"], args),
+                "launches_per_step": conv["launches"], "gflop_per_launch": round(conv["flops"] / 1e9 / conv["launches"], 2),
+                "us_per_launch": round(conv["ms"] * 1e3 / conv["launches"], 2)}
     kernels = {s["name"]: {"ms": round(s["ms"], 4), "launches": s["launches"],
                            "gflop": round(s["flops"] / 1e9, 3), "gbyte": round(s["bytes"] / 1e9, 4)} for s in stats}
 

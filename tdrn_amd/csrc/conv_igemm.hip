@@ -364,7 +364,8 @@ template <typename DT> static int launch_dt(const ConvParams &p, int phases, hip
     return launch_cfg<DT, 128, 32, 4, 1, 2>(p, phases, s);
 }
 
-// split-K second pass: out = epilogue(sum_s partial[s]) with the same views / flags as the fused epilogue
+// split-K second pass: out = epilogue(sum_s partial[s]) with the same views / flags as the fused epilogue.
+// One thread = 4 consecutive channels of one pixel (16-B slab reads, 8/16-B stores).
 template <typename DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, int phases)
 {
@@ -372,16 +373,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
     const int C4 = (p.Cout + 3) / 4;
     const long long total = (long long)phases * p.M * C4;
     const int HoWo = p.Ho * p.Wo;
+    const size_t slab = (size_t)phases * p.M * p.Npad;        // floats per K slice
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
         const long long r = i / C4;
         const int m = (int)(r % p.M), z = (int)(r / p.M);
+        const float *src = p.partial + ((size_t)z * p.M + m) * p.Npad + c;
         f32x4 v = *(const f32x4 *)(p.bias + c);
-        for (int sidx = 0; sidx < p.splits; ++sidx)
-            v += *(const f32x4 *)(p.partial + (((size_t)sidx * phases + z) * p.M + m) * p.Npad + c);
-        const int b = m / HoWo, rem = m - b * HoWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const long long eo = p.o_base + (z >> 1) * p.o_pr + (z & 1) * p.o_pc + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
+        for (int sidx = 0; sidx < p.splits; ++sidx) v += *(const f32x4 *)(src + sidx * slab);
+        long long eo;
+        if (p.out_linear) {
+            eo = p.o_base + (long long)m * p.o_cs + c;
+        } else {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            eo = p.o_base + (z >> 1) * p.o_pr + (z & 1) * p.o_pc + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
+        }
+        const bool full = c + 4 <= p.Cout;
+        if (!p.out_f32 && full) {                     // NHWC tensor in the net dtype: channel counts are multiples of 8
+            if (p.res) {
+                if constexpr (ES == 4) {
+                    const f32x4 rv = *(const f32x4 *)(p.res + eo * 4);
+                    v += rv;
+                } else {
+                    const uint2 rv = *(const uint2 *)(p.res + eo * 2);
+                    DT t0{(unsigned short)(rv.x & 0xffffu)}, t1{(unsigned short)(rv.x >> 16)}, t2{(unsigned short)(rv.y & 0xffffu)}, t3{(unsigned short)(rv.y >> 16)};
+                    v[0] += to_f32<DT>(t0); v[1] += to_f32<DT>(t1); v[2] += to_f32<DT>(t2); v[3] += to_f32<DT>(t3);
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if constexpr (ES == 4) {
+                *(f32x4 *)(p.out + eo * 4) = v;
+            } else {
+                const unsigned lo = (unsigned)from_f32<DT>(v[0]).v | ((unsigned)from_f32<DT>(v[1]).v << 16);
+                const unsigned hi = (unsigned)from_f32<DT>(v[2]).v | ((unsigned)from_f32<DT>(v[3]).v << 16);
+                *(uint2 *)(p.out + eo * 2) = make_uint2(lo, hi);
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (c + j >= p.Cout) break;
@@ -464,7 +496,7 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     }
     if (rc != TDRN_OK || p.splits == 1) return rc;
     const long long total = (long long)a.phases * p.M * ((p.Cout + 3) / 4);
-    dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256));
+    dim3 grid((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256));
     switch (a.dtype) {
         case TDRN_F32: hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, dim3(256), 0, s, p, a.phases); break;
         case TDRN_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), grid, dim3(256), 0, s, p, a.phases); break;

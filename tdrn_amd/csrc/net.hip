@@ -60,8 +60,8 @@ struct Op {
 };
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
-                            "deform_gemm_mfma", "softmax21", "layout"};
-enum { ST_CONV, ST_FIRST, ST_POOL, ST_L2, ST_DW, ST_OFFSET, ST_DEFORM, ST_SOFTMAX, ST_LAYOUT, ST_COUNT };
+                            "deform_gemm_mfma", "softmax21", "layout", "conv3x3_patch_mfma"};
+enum { ST_CONV, ST_FIRST, ST_POOL, ST_L2, ST_DW, ST_OFFSET, ST_DEFORM, ST_SOFTMAX, ST_LAYOUT, ST_CONV3, ST_COUNT };
 
 }  // namespace
 }  // namespace tdrn
@@ -571,6 +571,7 @@ struct tdrn_net {
         {
             size_t lane_bytes[kLanes] = {0, 0, 0, 0};
             for (Op &o : ops) {
+                if (o.kind == OP_CONV && o.pool_t >= 0 && conv_patch_enabled()) o.stat = ST_CONV3;
                 if (o.kind != OP_CONV || o.pool_t >= 0) continue;
                 const Tensor &ti = tensors[o.in];
                 ConvArgs a;
@@ -578,6 +579,11 @@ struct tdrn_net {
                 a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                 a.phases = o.phases; a.dtype = cfg.dtype; a.out_f32 = o.out_kind != OUT_TENSOR;
                 o.splitk = conv_splitk_choice(a);
+                a.o_cs = o.out_kind == OUT_TENSOR ? tensors[o.out].Cpad : 0;
+                a.o_rs = (long long)a.Wo * a.o_cs; a.o_bs = (long long)a.Ho * a.Wo * a.o_cs;
+                a.res = o.res >= 0 ? (const void *)1 : nullptr;
+                if (o.splitk == 1 && conv_patch_enabled() && patch_conv_supported(a) && a.H * a.W >= conv_patch_enabled() * 400)
+                    o.stat = ST_CONV3;
                 if (o.splitk > 1) {
                     const size_t per_sample = align_up((size_t)o.splitk * o.phases * a.Ho * a.Wo * o.Npad * sizeof(float), 256);
                     if (per_sample > lane_bytes[o.lane]) lane_bytes[o.lane] = per_sample;
@@ -1135,6 +1141,11 @@ int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries)
         k.launches = 1;
         k.flops = o.flops * net->last_batch;
         k.bytes = o.bytes * net->last_batch;
+        if (o.kind == OP_DEFORM)   // one launch covers the preceding deform ops of the other pyramid levels
+            for (int j = net->ev_op[i] - 1; j >= 0 && net->ops[j].kind == OP_DEFORM; --j) {
+                k.flops += net->ops[j].flops * net->last_batch;
+                k.bytes += net->ops[j].bytes * net->last_batch;
+            }
         k.ms = ms;
     }
     return n;
