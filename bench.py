@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
@@ -116,11 +117,36 @@ def main():
     det = Detect(21, 0, 200, 0.01, 0.45)
     scale = [500.0, 375.0, 500.0, 375.0]
 
+    # optional intra-GPU concurrency: the batch is cut into --streams slices, each with its own engine
+    # (shared weight blob), workspace and HIP stream, so that one slice's kernels fill the CUs another
+    # slice's tail leaves idle and Detect overlaps the other slices' convolutions.
+    NS = max(1, args.streams)
+    engines, streams, dets, xs = [eng], [torch.cuda.current_stream(dev)], [det], [x]
+    if NS > 1:
+        from tdrn_amd.engine import NetEngine
+        xs = list(torch.chunk(x, NS))
+        for i in range(1, NS):
+            e2 = NetEngine(**dict(net._engine_args, dtype=args.dtype))
+            e2.share_weights(eng)
+            engines.append(e2)
+            streams.append(torch.cuda.Stream(dev))
+            dets.append(Detect(21, 0, 200, 0.01, 0.45))
+
     def step():
-        r = eng.forward(x)
-        if args.no_detect:
-            return r["conf"]
-        return det.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
+        outs = []
+        if NS > 1:
+            start = torch.cuda.Event()
+            start.record(streams[0])
+        for i in range(NS):
+            with torch.cuda.stream(streams[i]):
+                if NS > 1 and i > 0:
+                    streams[i].wait_event(start)
+                r = engines[i].forward(xs[i])
+                outs.append(r["conf"] if args.no_detect else
+                            dets[i].forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale))
+        for i in range(1, NS):
+            streams[0].wait_stream(streams[i])
+        return outs
 
     for _ in range(args.warmup):
         step()

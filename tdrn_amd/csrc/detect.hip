@@ -11,7 +11,7 @@
 // candidates are ordered by (score desc, prior index asc).  Given identical fp32 boxes/scores
 // the keep lists equal cpu_nms's on tie-free scores.
 //
-// Pipeline (2 launches + 1 memset, no host sync):
+// Pipeline (3 launches + 1 memset, no host sync):
 //   detect_decode_kernel   : two-stage decode, normalised boxes + boxes*scale
 //   detect_nms_kernel      : per (image,class): score > conf_thresh compaction into LDS keys,
 //                            bitonic sort, wave-64 greedy NMS against an LDS-resident keep list,
@@ -179,25 +179,97 @@ __device__ __forceinline__ int wave_greedy_nms(int n, int cap, float bound, int 
     return nk < cap ? nk : cap;
 }
 
+// Workgroup version for Detect (256 threads): candidates are taken 256 at a time; every thread first
+// tests its candidate against the keep list as it stood at the start of the round (the long scan, now
+// spread over 4 waves), then wave 0 resolves the round 64 candidates at a time against only the boxes
+// kept DURING this round plus the pairwise bits.  Same decisions as the sequential algorithm.
+template <typename Get, typename Emit>
+__device__ __forceinline__ int block_greedy_nms(int n, int cap, float bound, Box *kept, unsigned char *alive_s, int *nk_s,
+                                                Get get, Emit emit)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *nk_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int nk0 = *nk_s;
+        if (nk0 >= cap) break;
+        const int pos = c0 + tid;
+        const bool valid = pos < n;
+        Box me = {0.f, 0.f, 0.f, 0.f, 1.f};
+        if (valid) get(pos, me);
+        bool alive = valid;
+        for (int i = 0; i < nk0 && alive; ++i)
+            if (over(iou_plus1(kept[i], me), bound, 0)) alive = false;
+        alive_s[tid] = alive ? 1 : 0;
+        __syncthreads();
+        if (wave == 0) {
+            int nk = nk0;
+            for (int sub = 0; sub < 4 && nk < cap && c0 + sub * 64 < n; ++sub) {
+                const int p2 = c0 + sub * 64 + lane;
+                const bool v2 = p2 < n;
+                Box b2 = {0.f, 0.f, 0.f, 0.f, 1.f};
+                if (v2) get(p2, b2);
+                bool al = v2 && alive_s[sub * 64 + lane];
+                for (int i = nk0; i < nk && al; ++i)        // boxes kept earlier in this round
+                    if (over(iou_plus1(kept[i], b2), bound, 0)) al = false;
+                unsigned long long sup = 0ull;
+                for (int i = 0; i < 63; ++i) {
+                    Box o;
+                    o.x1 = __shfl(b2.x1, i, 64); o.y1 = __shfl(b2.y1, i, 64);
+                    o.x2 = __shfl(b2.x2, i, 64); o.y2 = __shfl(b2.y2, i, 64); o.area = __shfl(b2.area, i, 64);
+                    if (i < lane && over(iou_plus1(o, b2), bound, 0)) sup |= 1ull << i;
+                }
+                const unsigned long long amask = __ballot(al);
+                unsigned long long km = 0ull;
+                for (int i = 0; i < 64; ++i) {
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)sup, i);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sup >> 32), i);
+                    const unsigned long long s_i = ((unsigned long long)hi << 32) | lo;
+                    if (((amask >> i) & 1ull) && (s_i & km) == 0ull) km |= 1ull << i;
+                }
+                const bool keepme = (km >> lane) & 1ull;
+                const int slot = nk + __popcll(km & ((1ull << lane) - 1ull));
+                if (keepme && slot < cap) {
+                    kept[slot] = b2;
+                    emit(slot, p2);
+                }
+                nk += __popcll(km);
+                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) *nk_s = nk;
+        }
+        __syncthreads();
+    }
+    const int nk = *nk_s;
+    return nk < cap ? nk : cap;
+}
+
 // ---- Detect: one workgroup per (image, class) segment -------------------------------------
 // detection.py:52-63.  The workgroup scans its class column of conf (score > conf_thresh, :53),
-// compacts the candidates into LDS as 64-bit keys (score bits : ~prior index), sorts them, and
-// wave 0 runs the greedy NMS against an LDS-resident keep list.
+// compacts the candidates into LDS as 64-bit keys (score bits : ~prior index), sorts them and runs the
+// greedy NMS against an LDS-resident keep list.  Two launches: the FAST one holds at most `kcap`
+// (2048) candidates in 16 KB of LDS so that every segment of a batch is resident at once; segments with
+// more candidates raise overflow[seg] and are redone by the second launch with a P-sized key buffer
+// (whose other workgroups exit at once).
 __global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
                                                          const float *__restrict__ conf, int P, int C, int top_k,
-                                                         float conf_thresh, float bound, int kcap,
-                                                         float *__restrict__ out, int *__restrict__ counts_out)
+                                                         float conf_thresh, float bound, int kcap, int pass,
+                                                         int *__restrict__ overflow, float *__restrict__ out,
+                                                         int *__restrict__ counts_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
     unsigned long long *sk = dsm;
     Box *kept = (Box *)(dsm + kcap);
     int *cnt = (int *)(kept + top_k);
+    unsigned char *alive_s = (unsigned char *)(cnt + 4);
     const int seg = blockIdx.x;          // b*C + cl
     const int cl = seg % C, b = seg / C;
     if (cl == 0) {
-        if (counts_out && threadIdx.x == 0) counts_out[seg] = 0;
+        if (pass == 0 && counts_out && threadIdx.x == 0) counts_out[seg] = 0;
         return;
     }
+    if (pass == 1 && !overflow[seg]) return;
     if (threadIdx.x == 0) *cnt = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -205,19 +277,20 @@ __global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict
     for (int p0 = 0; p0 < P; p0 += 256) {
         const int p = p0 + threadIdx.x;
         const float sc = p < P ? col[(size_t)p * C] : 0.f;
-        const bool pass = p < P && sc > conf_thresh;
-        const unsigned long long m = __ballot(pass);
+        const bool pass_thr = p < P && sc > conf_thresh;
+        const unsigned long long m = __ballot(pass_thr);
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
         base = __shfl(base, 0, 64);
-        if (pass)
-            sk[base + __popcll(m & ((1ull << lane) - 1ull))] =
-                ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pass_thr && idx < kcap)
+            sk[idx] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
     }
     __syncthreads();
     const int n = *cnt;
-    if (n == 0) {
-        if (counts_out && threadIdx.x == 0) counts_out[seg] = 0;
+    if (pass == 0 && threadIdx.x == 0) overflow[seg] = n > kcap ? 1 : 0;
+    if (n == 0 || n > kcap) {
+        if (n == 0 && counts_out && threadIdx.x == 0) counts_out[seg] = 0;
         return;
     }
     int N = 64;
@@ -225,12 +298,11 @@ __global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict
     for (int i = n + threadIdx.x; i < N; i += 256) sk[i] = 0ull;
     __syncthreads();
     bitonic_sort_desc(sk, N, threadIdx.x, 256);
-    if (threadIdx.x >= 64) return;
     const float *sb = sboxes + (size_t)b * P * 4;
     const float *nb = boxes + (size_t)b * P * 4;
     float *orow = out + (size_t)seg * top_k * 5;
-    const int nk = wave_greedy_nms(
-        n, top_k, bound, 0, kept,
+    const int nk = block_greedy_nms(
+        n, top_k, bound, kept, alive_s, cnt + 1,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
             const f32x4 v = *(const f32x4 *)(sb + (size_t)p * 4);
@@ -252,8 +324,8 @@ static int next_pow2(int v) { int n = 64; while (n < v) n <<= 1; return n; }
 
 size_t detect_workspace_bytes(int B, int P, int C, int top_k)
 {
-    (void)top_k; (void)C;
-    return align_up((size_t)B * P * 4 * sizeof(float), 256) * 2;                  // boxes, boxes*scale
+    (void)top_k;
+    return align_up((size_t)B * P * 4 * sizeof(float), 256) * 2 + align_up((size_t)B * C * sizeof(int), 256);   // boxes, boxes*scale, overflow flags
 }
 
 int launch_detect(const float *loc, const float *conf, const float *priors, const float *arm_loc, const float *scale4,
@@ -264,12 +336,15 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
     if (nms_thresh <= 0) return TDRN_E_VALUE;
     if (B <= 0 || P <= 0 || C < 2 || top_k <= 0) return TDRN_E_ARG;
     if (ws_bytes < detect_workspace_bytes(B, P, C, top_k)) return TDRN_E_WORKSPACE;
-    const int kcap = next_pow2(P);
-    const size_t lds = (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 16;
-    if (lds > 160 * 1024) return TDRN_E_UNSUPPORTED;
+    const int kcap_big = next_pow2(P);
+    const int kcap_fast = kcap_big < 2048 ? kcap_big : 2048;
+    const size_t tail = (size_t)top_k * sizeof(Box) + 32 + 256;      // keep list, counters, alive flags
+    const size_t lds_big = (size_t)kcap_big * 8 + tail, lds_fast = (size_t)kcap_fast * 8 + tail;
+    if (lds_big > 160 * 1024) return TDRN_E_UNSUPPORTED;
     char *w = (char *)ws;
     float *boxes = (float *)w;  w += align_up((size_t)B * P * 4 * sizeof(float), 256);
-    float *sboxes = (float *)w;
+    float *sboxes = (float *)w; w += align_up((size_t)B * P * 4 * sizeof(float), 256);
+    int *overflow = (int *)w;
     // (double)ovr >= thresh  <=>  ovr >= bound, bound = smallest fp32 whose double value >= thresh
     float bound = (float)nms_thresh;
     if ((double)bound < nms_thresh) bound = nextafterf(bound, INFINITY);
@@ -282,8 +357,11 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
         TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds, s, boxes, sboxes, conf, P, C, top_k,
-                       conf_thresh, bound, kcap, out, counts_out);
+    hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_fast, s, boxes, sboxes, conf, P, C, top_k,
+                       conf_thresh, bound, kcap_fast, 0, overflow, out, counts_out);
+    if (kcap_big > kcap_fast)
+        hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_big, s, boxes, sboxes, conf, P, C, top_k,
+                           conf_thresh, bound, kcap_big, 1, overflow, out, counts_out);
     return hip_status(hipGetLastError());
 }
 

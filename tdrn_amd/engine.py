@@ -73,6 +73,16 @@ class NetEngine(object):
         n = self.lib.tdrn_net_weight_bytes(self.handle)
         self.weights = torch.zeros(n, dtype=torch.uint8, device=self.device)
 
+    def share_weights(self, other):
+        """Use another engine's packed blob (same model/dtype): several engines -- e.g. one per HIP stream --
+        can run concurrently on one GPU from a single copy of the weights."""
+        if other.weights is None:
+            raise RuntimeError("the other engine has no packed weights")
+        if self.lib.tdrn_net_weight_bytes(self.handle) != other.weights.numel():
+            raise ValueError("engines differ in model or dtype")
+        self.weights, self.device = other.weights, other.device
+        check(self.lib.tdrn_net_adopt_weights(self.handle))
+
     def broadcast_weights(self, src=0):
         """One RCCL broadcast of the packed blob over xGMI; every other rank adopts it (no
         per-frame collective follows).  Call after load() on rank `src`, instead of load() elsewhere."""
