@@ -126,6 +126,16 @@ TDRN_API int tdrn_detect(const float *loc, const float *conf, const float *prior
                          int32_t *counts_out, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* Preprocess -- replaces base_transform + the channel swap of
+ *     data/__init__.py:7-12 (cv2.resize(image,(S,S)) -> float32 -> -= mean) and data/voc0712.py:467-468
+ *     (BGR -> RGB, HWC -> CHW); test_video.py:103-105 skips the swap (to_rgb = 0).
+ *   frames (B, H0, W0, 3) uint8 BGR device; out (B, 3, S, S) fp32 NCHW device.
+ *   Resize = OpenCV's INTER_LINEAR for 8-bit images (half-pixel centres, 11-bit fixed-point
+ *   coefficients, uint8 result) restated from imgproc/resize.cpp; cv2 itself is not available in
+ *   the build image, so this piece is "parity unpinned" (oracle = oracle.base_transform_u8). */
+TDRN_API int tdrn_preprocess(const uint8_t *frames, int B, int H0, int W0, int S, const float mean_bgr[3],
+                             int to_rgb, float *out, void *stream);
+
 /* ========================================================================================
  * (iii) Whole-network forward -- replaces build_net(...)/RefineSSD.forward:
  *     model/dualrefinedet_vggbn.py:10-117,119-206,217-222   (TDRN_DRN_VGGBN)

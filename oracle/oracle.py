@@ -163,3 +163,36 @@ def softmax_rows(x):
     lib().orc_softmax_rows(x.ctypes.data_as(C.c_void_p), x.shape[0], x.shape[1],
                            out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def base_transform_u8(image, size, mean_bgr, to_rgb=False):
+    """data/__init__.py:7-12 + data/voc0712.py:467-468 for uint8 BGR frames (B,H,W,3) -> (B,3,S,S) fp32.
+    cv2.resize(INTER_LINEAR, 8-bit) restated from OpenCV imgproc/resize.cpp (11-bit fixed-point coefficients;
+    vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  PARITY UNPINNED: cv2 is not installed
+    in the build image, so this restatement could not be checked against cv2 itself."""
+    img = np.asarray(image, np.uint8)
+    if img.ndim == 3:
+        img = img[None]
+    B, H0, W0, _ = img.shape
+
+    def coef(n_dst, n_src):
+        d = np.arange(n_dst)
+        f = ((d + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        lo = s < 0
+        f[lo], s[lo] = 0, 0
+        hi = s >= n_src - 1
+        f[hi], s[hi] = 0, n_src - 1
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, np.minimum(s + 1, n_src - 1), c0, c1
+    x0, x1, a0, a1 = coef(size, W0)
+    y0, y1, b0, b1 = coef(size, H0)
+    src = img.astype(np.int64)
+    h = src[:, :, x0, :] * a0[None, None, :, None] + src[:, :, x1, :] * a1[None, None, :, None]     # (B,H0,S,3)
+    v = (((b0[None, :, None, None] * (h[:, y0] >> 4)) >> 16) + ((b1[None, :, None, None] * (h[:, y1] >> 4)) >> 16) + 2) >> 2
+    v = np.clip(v, 0, 255).astype(np.float32) - np.asarray(mean_bgr, np.float32)[None, None, None, :]
+    if to_rgb:
+        v = v[..., ::-1]
+    return np.ascontiguousarray(v.transpose(0, 3, 1, 2)).astype(np.float32)

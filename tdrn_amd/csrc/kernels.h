@@ -76,6 +76,8 @@ int launch_nhwc_to_nchw_f32(const float *in, long long in_bs, long long in_ps, f
                             int C, int HW, hipStream_t s);   // fp32 "NHWC view" -> fp32 NCHW
 // NHWC (channel stride Cpad, dtype DT or fp32) -> fp32 NCHW
 int launch_nhwc_any_to_nchw_f32(const void *in, int dtype, int Cpad, float *out, int B, int C, int HW, hipStream_t s);
+int launch_preprocess(const unsigned char *in, int B, int H0, int W0, int S, const float *mean_bgr, int to_rgb, float *out,
+                      hipStream_t s);
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

@@ -434,6 +434,59 @@ int launch_nhwc_any_to_nchw_f32(const void *in, int dtype, int Cpad, float *out,
     return hip_status(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Preprocess: uint8 BGR HWC -> cv2-style bilinear resize (fixed point) -> -mean -> (RGB) -> fp32 NCHW.
+// OpenCV imgproc/resize.cpp, 8-bit INTER_LINEAR: fx = (dx+0.5)*scale-0.5, 11-bit coefficients
+// (saturate_cast<short>(w*2048)), horizontal sums in int, vertical
+//   dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cv_coef(int d, double scale, int n_src, int &s0, int &c0, int &c1)
+{
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int sidx = (int)floorf(f);
+    f -= (float)sidx;
+    if (sidx < 0) { f = 0.f; sidx = 0; }
+    if (sidx >= n_src - 1) { f = 0.f; sidx = n_src - 1; }
+    s0 = sidx;
+    c0 = (int)rintf((1.f - f) * 2048.f);
+    c1 = (int)rintf(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__restrict__ in, int B, int H0, int W0, int S,
+                                                         float m0, float m1, float m2, int to_rgb, float *__restrict__ out)
+{
+    const long long total = (long long)B * S * S;
+    const double sx = (double)W0 / S, sy = (double)H0 / S;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int dx = (int)(i % S), dy = (int)((i / S) % S), b = (int)(i / ((long long)S * S));
+        int x0, a0, a1, y0, b0, b1;
+        cv_coef(dx, sx, W0, x0, a0, a1);
+        cv_coef(dy, sy, H0, y0, b0, b1);
+        const int x1 = x0 + 1 < W0 ? x0 + 1 : x0, y1 = y0 + 1 < H0 ? y0 + 1 : y0;
+        const unsigned char *r0 = in + (((size_t)b * H0 + y0) * W0) * 3, *r1 = in + (((size_t)b * H0 + y1) * W0) * 3;
+        const float mean[3] = {m0, m1, m2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;     // horizontal pass, rows y0 / y1
+            const int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            const float px = (float)(v < 0 ? 0 : (v > 255 ? 255 : v)) - mean[c];
+            const int oc = to_rgb ? 2 - c : c;
+            out[(((size_t)b * 3 + oc) * S + dy) * S + dx] = px;
+        }
+    }
+}
+
+int launch_preprocess(const unsigned char *in, int B, int H0, int W0, int S, const float *mean_bgr, int to_rgb, float *out,
+                      hipStream_t s)
+{
+    const long long total = (long long)B * S * S;
+    if (total <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, s, in, B, H0, W0, S, mean_bgr[0], mean_bgr[1], mean_bgr[2], to_rgb, out);
+    return hip_status(hipGetLastError());
+}
+
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s)
 {
     return hip_status(hipMemsetAsync(p, 0, bytes, s));

@@ -1,0 +1,38 @@
+"""Key-frame driver of the temporal refinement network (TRN): the per-frame protocol of
+evaluate_trn.py:438-467 / test_video_trn.py:83-103 around the static and temporal SSD4Scale nets.
+
+Every `interval` frames (or on a new video) the static net produces refined anchors (its loc output,
+scaled by `loose`) and the raw loc maps; the temporal net turns the loc maps into deformable offsets
+once and reuses them until the next key frame.  State per stream = (anchors, loc maps / offsets), so a
+clip must stay on one rank (tdrn_amd.dist shards by clip)."""
+
+
+class TRNDriver(object):
+    def __init__(self, static_net, temporal_net, detector, priors, interval=4, loose=1.0, deform=True):
+        self.static_net, self.net, self.detector, self.priors = static_net, temporal_net, detector, priors
+        self.interval, self.loose, self.deform = int(interval), float(loose), bool(deform)
+        self.reset()
+
+    def reset(self):
+        self.pre_video_name, self.current_i = None, 0
+        self.static_out, self.ref_loc, self.offset_list = None, [], []
+        self.key_frames = 0
+
+    def step(self, x, video_name=None, scale=None):
+        """x: (1,3,S,S) preprocessed frame.  Returns Detect output (1, C, top_k, 5)."""
+        new_video = video_name != self.pre_video_name
+        if self.static_out is None or new_video or self.current_i % self.interval == 0:
+            self.static_out = list(self.static_net(x, ret_loc=self.deform))
+            self.static_out[0] = self.static_out[0] * self.loose
+            self.key_frames += 1
+            if self.deform:
+                self.ref_loc, self.offset_list = self.static_out[2], []
+            if new_video:
+                self.pre_video_name, self.current_i = video_name, 0
+        need_off = self.deform and not self.offset_list
+        out = self.net(x, ref_loc=self.ref_loc, offset_list=self.offset_list, ret_off=need_off)
+        if len(out) == 3:
+            self.offset_list, self.ref_loc = out[2], []
+        dets = self.detector.forward(out[0], out[1], self.priors, arm_loc_data=self.static_out[0], scale=scale)
+        self.current_i += 1
+        return dets

@@ -262,3 +262,27 @@ def test_drn_vggbn_512_fp32_and_fp16():
     e = (o16[:1].cpu() - r_odm).abs().flatten()
     assert float(e.mean()) < 0.006 and float(torch.quantile(e[::7], 0.999)) < 0.06
     assert float((c16[:16320].cpu() - r_conf).abs().mean()) < 6e-4
+
+
+def test_trn_driver_key_frame_protocol():
+    """evaluate_trn.py:438-467: static net on key frames only, cached offsets in between, anchors from the
+    static net's loc; the driver's detections equal the hand-written sequence of calls."""
+    from tdrn_amd.trn import TRNDriver
+    stat, _ = _build("ssd4scale_mobile", (320, 21, 1024, False), seed=0)
+    temp, _ = _build("ssd4scale_mobile", (320, 21, 1024, True), seed=1)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.3, 0.45)
+    drv = TRNDriver(stat, temp, det, pri, interval=4, loose=1.0, deform=True)
+    clip = torch.from_numpy(synth.synth_frames(6, 320, seed=41)).to(DEV)
+    outs = [drv.step(clip[f:f + 1], video_name="v0") for f in range(6)]
+    assert drv.key_frames == 2                      # frames 0 and 4
+    s0 = stat(clip[0:1], ret_loc=True)
+    t0 = temp(clip[0:1], ref_loc=s0[2], ret_off=True)
+    t2 = temp(clip[2:3], offset_list=t0[2])
+    ref2 = det.forward(t2[0], t2[1], pri, arm_loc_data=s0[0])
+    assert torch.equal(outs[2], ref2)
+    s4 = stat(clip[4:5], ret_loc=True)
+    t5 = temp(clip[5:6], ref_loc=s4[2])
+    assert torch.equal(outs[5], det.forward(t5[0], t5[1], pri, arm_loc_data=s4[0]))
+    drv.step(clip[0:1], video_name="v1")            # a new video forces a key frame
+    assert drv.key_frames == 3 and drv.current_i == 1

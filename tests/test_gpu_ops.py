@@ -203,3 +203,23 @@ def test_detect_empty_and_errors():
         det.forward(torch.zeros(1, P, 4, device=DEV), _cu(conf[:10]), pri)
     lib = _lib.lib()
     assert lib.tdrn_detect(None, None, None, None, None, 1, P, 21, 200, 0.01, 0.45, None, None, None, 0, None) == -1
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocess and the TRN key-frame driver (rank 2)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,size,rgb", [((375, 500), 320, True), ((480, 640), 320, False), ((300, 300), 512, True),
+                                            ((1080, 1920), 320, True), ((320, 320), 320, True)])
+def test_preprocess_matches_oracle_bit_exact(shape, size, rgb):
+    from tdrn_amd.data import base_transform, BaseTransform, MEANS
+    rng = np.random.Generator(np.random.PCG64(shape[0] + size))
+    frames = rng.integers(0, 256, (2,) + shape + (3,), dtype=np.uint8)
+    ref = orc.base_transform_u8(frames, size, MEANS, rgb)
+    got = base_transform(torch.from_numpy(frames).to(DEV), size, MEANS, rgb).cpu().numpy()
+    assert got.shape == (2, 3, size, size)
+    assert np.array_equal(got, ref)
+    one, _, _ = BaseTransform(size, MEANS, rgb)(torch.from_numpy(frames[0]).to(DEV))
+    assert np.array_equal(one.cpu().numpy()[0], ref[0])
+    if shape == (320, 320):        # identity resize: exactly pixel - mean
+        exp = frames.astype(np.float32) - np.asarray(MEANS, np.float32)
+        assert np.array_equal(got, exp[..., ::-1].transpose(0, 3, 1, 2) if rgb else exp.transpose(0, 3, 1, 2))
