@@ -27,10 +27,12 @@ struct DeformParams {
     int M, H, W, Cin, Ho, Wo, Cout, Npad, split;
     float *out0, *out1;
     long long o0_bs, o0_ps, o1_bs, o1_ps;
+    int accumulate;   // 1: outputs are pre-zeroed and this problem atomically adds its partial result
+    int pad2_;
 };
 // several independent problems (the four pyramid levels) in ONE launch: their K loops are
 // latency-bound per workgroup, so running them side by side costs the time of the longest.
-constexpr int kMaxDeformProblems = 4;
+constexpr int kMaxDeformProblems = 8;
 struct DeformMulti {
     DeformParams p[kMaxDeformProblems];
     int block_start[kMaxDeformProblems + 1];
@@ -261,8 +263,9 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
         if (m >= p.M) break;
         const int b = m / HoWo, pix = m - b * HoWo;
         const float v = *(const float *)(smem + row * CS + c * 4);
-        if (c < p.split) p.out0[b * p.o0_bs + pix * p.o0_ps + c] = v;
-        else p.out1[b * p.o1_bs + pix * p.o1_ps + (c - p.split)] = v;
+        float *dst = c < p.split ? p.out0 + b * p.o0_bs + pix * p.o0_ps + c : p.out1 + b * p.o1_bs + pix * p.o1_ps + (c - p.split);
+        if (p.accumulate) atomicAdd(dst, v);      // exactly two addends land on a zeroed value: order-independent
+        else *dst = v;
     }
 }
 
@@ -305,21 +308,38 @@ static int fill_params(const DeformArgs &a, DeformParams &p)
     return TDRN_OK;
 }
 
-// all problems must share dtype and Npad (they do: the pyramid levels of one model)
-int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s)
+// all problems must share dtype and Npad (they do: the pyramid levels of one model).
+// split_branches: a two-branch problem (3x3 + 5x5 heads) becomes two single-branch work items that
+// atomically add into PRE-ZEROED outputs.  All workgroups have the same K-loop length per branch and the
+// kernel is latency-bound per workgroup, so 532 two-branch workgroups on 512 resident slots cost two
+// full rounds; as 532 long (25-tap) + 532 short (9-tap) items dispatched longest-first they pack tightly.
+int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_branches)
 {
-    if (!args || n < 1 || n > kMaxDeformProblems) return TDRN_E_ARG;
+    if (!args || n < 1 || n > 4) return TDRN_E_ARG;
     DeformMulti mp;
     mp.n = 0;
     mp.block_start[0] = 0;
-    for (int i = 0; i < n; ++i) {
-        if (args[i].dtype != args[0].dtype || args[i].Npad != args[0].Npad) return TDRN_E_UNSUPPORTED;
-        DeformParams p;
-        TDRN_TRY(fill_params(args[i], p));
-        if (p.M <= 0) continue;
-        mp.p[mp.n] = p;
-        mp.block_start[mp.n + 1] = mp.block_start[mp.n] + cdiv(p.M, 128);
-        ++mp.n;
+    for (int pass = 0; pass < 2; ++pass) {           // pass 0: the longer branch of every problem, pass 1: the rest
+        for (int i = 0; i < n; ++i) {
+            if (args[i].dtype != args[0].dtype || args[i].Npad != args[0].Npad) return TDRN_E_UNSUPPORTED;
+            DeformArgs a = args[i];
+            const bool two = a.n_branches == 2 && split_branches;
+            if (!two && pass == 1) continue;
+            if (two) {
+                const int t0 = a.br[0].kh * a.br[0].kw, t1 = a.br[1].kh * a.br[1].kw;
+                const int longer = t1 > t0 ? 1 : 0;
+                a.br[0] = args[i].br[pass == 0 ? longer : 1 - longer];
+                a.n_branches = 1;
+            }
+            DeformParams p;
+            TDRN_TRY(fill_params(a, p));
+            p.accumulate = two ? 1 : 0;
+            p.pad2_ = 0;
+            if (p.M <= 0) continue;
+            mp.p[mp.n] = p;
+            mp.block_start[mp.n + 1] = mp.block_start[mp.n] + cdiv(p.M, 128);
+            ++mp.n;
+        }
     }
     if (mp.n == 0) return TDRN_OK;
     for (int i = mp.n; i < kMaxDeformProblems; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
@@ -331,6 +351,6 @@ int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s)
     return TDRN_E_ARG;
 }
 
-int launch_deform(const DeformArgs &a, hipStream_t s) { return launch_deform_multi(&a, 1, s); }
+int launch_deform(const DeformArgs &a, hipStream_t s) { return launch_deform_multi(&a, 1, s, 0); }
 
 }  // namespace tdrn

@@ -108,7 +108,8 @@ struct DeformArgs {
 };
 int launch_deform(const DeformArgs &a, hipStream_t s);
 // up to 4 independent problems (same dtype / Npad) in one launch
-int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s);
+// split_branches = 1: two-branch problems run as two work items that atomicAdd into PRE-ZEROED outputs
+int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_branches);
 int deform_n_pad(int cout);
 
 // ---------------------------------------------------------------------------------------------

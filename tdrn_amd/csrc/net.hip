@@ -90,7 +90,7 @@ struct tdrn_net {
     static constexpr int kLanes = 4;
     size_t splitk_off[kLanes] = {0, 0, 0, 0};   // per-lane split-K slab region (bytes per sample from workspace start)
     int cur_lane = 0;
-    bool use_lanes = true, lanes_ready = false;
+    bool use_lanes = true, lanes_ready = false, deform_split = true;
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
@@ -596,6 +596,8 @@ struct tdrn_net {
         }
         const char *e = getenv("TDRN_STREAMS");
         if (e && atoi(e) <= 1) use_lanes = false;
+        const char *ds = getenv("TDRN_DEFORM_SPLIT");
+        if (ds && atoi(ds) == 0) deform_split = false;
         tensor_lane.assign(tensors.size(), 0);
         tensor_shared.assign(tensors.size(), 0);
         for (const Op &o : ops) {
@@ -943,7 +945,13 @@ struct tdrn_net {
                     a.split = 12; a.dtype = cfg.dtype;
                     dargs[n_dargs++] = a;
                     if (!deform_batched) {      // all pyramid levels in one launch
-                        rc = launch_deform_multi(dargs, n_dargs, s);
+                        const bool split = o.n_branches == 2 && deform_split;
+                        if (split) {             // the two branches accumulate into zeroed outputs
+                            float *locbase0 = o.out_kind == OUT_ARM_LOC ? io->arm_loc : io->odm_loc;
+                            TDRN_HIP_TRY(hipMemsetAsync(locbase0, 0, (size_t)B * P * 4 * sizeof(float), s));
+                            TDRN_HIP_TRY(hipMemsetAsync(io->conf, 0, (size_t)B * P * C * sizeof(float), s));
+                        }
+                        rc = launch_deform_multi(dargs, n_dargs, s, split ? 1 : 0);
                         n_dargs = 0;
                     }
                     break;
