@@ -112,8 +112,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     constexpr int SSTRIDE = BNH * ES + 16;              // staging row stride (bytes)
     constexpr int OFF_W = 2 * kPatchBytes;
     constexpr int OFF_S = OFF_W + 3 * WBYTES;
-    constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the current item (one LDS-DMA piece)
-    constexpr int LDS = OFF_B + 1024;
+    constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the current / next item (two 1-KiB LDS-DMA pieces)
+    constexpr int LDS = OFF_B + 2048;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
 
@@ -236,6 +236,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             load_weights();
             if (n_steps > 1) load_weights();
             next_patch_chunk();
+            if (lw == 0 && live)
+                glds(lane < BN / 4 ? (const char *)(p.bias + (item0 % p.n_tiles) * BN) + lane * 16 : p.zero, smem + OFF_B);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -264,11 +266,11 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                     default: load_patch(10, ccoff, dstbuf); issued += 1; break;
                 }
             }
-            if (lw == 0 && c_cc == 0 && tap == 6) {
-                // the current item's bias -> LDS (read by the consumers' epilogue; the previous item's
-                // epilogue ended before this item's first barrier)
-                const int nt = (item0 + c_it * istride) % p.n_tiles;
-                if (live) glds(lane < BN / 4 ? (const char *)(p.bias + nt * BN) + lane * 16 : p.zero, smem + OFF_B);
+            if (lw == 0 && c_cc == nchunks - 1 && tap == 6 && c_it + 1 < n_it) {
+                // the NEXT item's bias -> the other LDS bias slot (the consumers initialise their
+                // accumulators from it when that item starts; this item reads slot c_it & 1)
+                const int nt = (item0 + (c_it + 1) * istride) % p.n_tiles;
+                if (live) glds(lane < BN / 4 ? (const char *)(p.bias + nt * BN) + lane * 16 : p.zero, smem + OFF_B + ((c_it + 1) & 1) * 1024);
                 issued += 1;
             }
             wait_vmcnt(live ? issued : 0);
@@ -354,22 +356,24 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             const long long m = tile_pix0 + i;
             return m < p.M ? m : -1;
         };
-        // one 4-cout quad of one accumulator tile -> (+bias, ReLU, convert) -> staging row
+        // one 4-cout quad of one accumulator tile -> (ReLU, convert) -> staging row (bias is already in)
         auto stage_quad = [&](const f32x16 &t, int ci, int g, int srow) {
-            const f32x4 bv = *(const f32x4 *)(smem + OFF_B + (chalf * BNH + ci * 32 + 8 * g + 4 * hh) * 4);
             float q4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = t[4 * g + j] + bv[j];
-                q4[j] = p.relu ? fmaxf(v, 0.f) : v;
-            }
+            for (int j = 0; j < 4; ++j) q4[j] = p.relu ? fmaxf(t[4 * g + j], 0.f) : t[4 * g + j];
             char *d = stg + srow * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * ES;
             if constexpr (ES == 4) {
                 *(f32x4 *)d = f32x4{q4[0], q4[1], q4[2], q4[3]};
+            } else if constexpr (sizeof(DT) == 2 && __is_same(DT, bf16_t)) {
+                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                typedef float fl2 __attribute__((ext_vector_type(2)));
+                const bf2 lo = __builtin_convertvector(fl2{q4[0], q4[1]}, bf2), hi = __builtin_convertvector(fl2{q4[2], q4[3]}, bf2);
+                *(uint2 *)d = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
             } else {
-                const unsigned lo = (unsigned)from_f32<DT>(q4[0]).v | ((unsigned)from_f32<DT>(q4[1]).v << 16);
-                const unsigned hi = (unsigned)from_f32<DT>(q4[2]).v | ((unsigned)from_f32<DT>(q4[3]).v << 16);
-                *(uint2 *)d = make_uint2(lo, hi);
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                typedef float fl2 __attribute__((ext_vector_type(2)));
+                const h2 lo = __builtin_convertvector(fl2{q4[0], q4[1]}, h2), hi = __builtin_convertvector(fl2{q4[2], q4[3]}, h2);
+                *(uint2 *)d = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
             }
         };
         if (p.out && !(TDRN_PATCH_ABLATE & 4)) {
@@ -479,19 +483,25 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) MmaP<DT>::run(wf[ci], pf[pt], acc[ci][pt]);
     };
-    auto zero_acc = [&]() {
+    // accumulators start at the bias (staged into LDS by loader wave 0 one item ahead)
+    auto init_acc = [&](int it_) {
+        const char *bsrc = smem + OFF_B + (it_ & 1) * 1024;
 #pragma unroll
         for (int ci = 0; ci < WC; ++ci)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4 *)(bsrc + (chalf * BNH + ci * 32 + 8 * g + 4 * hh) * 4);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[ci][pt][e] = 0.f;
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ci][pt][4 * g + j] = bv[j];
+            }
     };
 
     __builtin_amdgcn_s_barrier();                       // prologue operands landed
     if (n_it > 0) {
         setup_item(0);
-        zero_acc();
+        init_acc(0);
         load_frags(wfA, pfA, 0);
     }
     int it = 0, cc = 0, tap = 0, tq = 0, delta = 0, wslot = 0, pbuf = 0;
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             ++it;
             if (it < n_it) {
                 setup_item(it);
-                zero_acc();
+                init_acc(it);
             }
         }
     }

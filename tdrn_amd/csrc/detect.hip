@@ -7,15 +7,20 @@
 //
 // Bit-exactness: every fp32 operation is issued un-fused and in the reference's order
 // (__fmul_rn / __fadd_rn / __fsub_rn / __fdiv_rn), the IoU-vs-threshold test compares the fp32
-// IoU against the DOUBLE threshold (pre-rounded on the host to the equivalent fp32 bound), and
-// candidates are ordered by (score desc, prior index asc).  Given identical fp32 boxes/scores
-// the keep lists equal cpu_nms's on tie-free scores.
+// IoU against the DOUBLE threshold (pre-rounded on the host to the equivalent fp32 bound, NmsRule), and
+// candidates are ordered by (score desc, prior index asc).  Given identical fp32 boxes/scores the keep
+// lists equal cpu_nms's on tie-free scores.
 //
-// Pipeline (3 launches + 1 memset, no host sync):
-//   detect_decode_kernel   : two-stage decode, normalised boxes + boxes*scale
-//   detect_nms_kernel      : per (image,class): score > conf_thresh compaction into LDS keys,
-//                            bitonic sort, wave-64 greedy NMS against an LDS-resident keep list,
-//                            early exit at top_k, pack output rows
+// Pipeline (3 launches, no memset, no host sync):
+//   detect_decode_kernel     : two-stage decode, normalised boxes + boxes*scale; scores -> class-major rows
+//   detect_select_nms_kernel : per (image,class): class row -> LDS; then, up to 2048 candidates at a time in
+//                              descending score (radix-select of a score threshold, compaction, bitonic
+//                              sort), greedy NMS against an LDS-resident keep list until top_k boxes are
+//                              kept or the candidates run out; pack + zero-fill the output rows
+//   detect_nms_kernel        : redo, with one full sort, of segments where >2048 candidates tie on score
+#include <cmath>
+#include <cstring>
+
 #include "kernels.h"
 
 namespace tdrn {
@@ -73,14 +78,25 @@ int launch_center_size(const float *boxes, int P, float *out, hipStream_t s)
     return hip_status(hipGetLastError());
 }
 
-// detection.py:43-48 (+ :59 boxes*scale)
+// detection.py:43-48 (+ :59 boxes*scale).  The same launch transposes the (B*P, C) score rows into
+// class-major rows scoresT[b][cl][p] (through an LDS tile, both sides coalesced) so that the per-class
+// workgroups of the NMS launch read 4*P contiguous bytes instead of a C-strided column.
 __global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restrict__ loc, const float *__restrict__ arm,
-                                                            const float *__restrict__ priors, int B, int P, f32x4 scale,
-                                                            float *__restrict__ boxes, float *__restrict__ sboxes)
+                                                            const float *__restrict__ priors, const float *__restrict__ conf,
+                                                            int B, int P, int C, f32x4 scale, float *__restrict__ boxes,
+                                                            float *__restrict__ sboxes, float *__restrict__ scoresT)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)B * P) return;
-    const int p = (int)(i % P);
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // 256 rows x (C|1) floats
+    const long long i0 = (long long)blockIdx.x * 256, total = (long long)B * P;
+    const long long i = i0 + threadIdx.x;
+    const int Cs = C | 1;
+    const long long rows = total - i0 < 256 ? total - i0 : 256;
+    const float *src = conf + i0 * C;
+    for (int k = threadIdx.x; k < (int)rows * C; k += 256) tile[(k / C) * Cs + k % C] = src[k];
+    __syncthreads();
+    if (i >= total) return;
+    const int p = (int)(i % P), b = (int)(i / P);
+    for (int cl = 0; cl < C; ++cl) scoresT[((size_t)b * C + cl) * P + p] = tile[threadIdx.x * Cs + cl];
     const f32x4 pr = *(const f32x4 *)(priors + (size_t)p * 4);
     float anchor[4] = {pr[0], pr[1], pr[2], pr[3]};
     if (arm) {
@@ -90,55 +106,147 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restr
         center_size_one(t, anchor);
     }
     const f32x4 l = *(const f32x4 *)(loc + (size_t)i * 4);
-    float lf[4] = {l[0], l[1], l[2], l[3]}, b[4];
-    decode_one(lf, anchor, 0.1f, 0.2f, b);
-    *(f32x4 *)(boxes + (size_t)i * 4) = f32x4{b[0], b[1], b[2], b[3]};
+    float lf[4] = {l[0], l[1], l[2], l[3]}, bx[4];
+    decode_one(lf, anchor, 0.1f, 0.2f, bx);
+    *(f32x4 *)(boxes + (size_t)i * 4) = f32x4{bx[0], bx[1], bx[2], bx[3]};
     *(f32x4 *)(sboxes + (size_t)i * 4) =
-        f32x4{__fmul_rn(b[0], scale[0]), __fmul_rn(b[1], scale[1]), __fmul_rn(b[2], scale[2]), __fmul_rn(b[3], scale[3])};
+        f32x4{__fmul_rn(bx[0], scale[0]), __fmul_rn(bx[1], scale[1]), __fmul_rn(bx[2], scale[2]), __fmul_rn(bx[3], scale[3])};
 }
 
 // ---- shared device pieces -------------------------------------------------------------------
+// Bitonic sort (descending) of N = 2^k >= 128 keys in LDS by 256 threads.  Compare-exchange i touches
+// a = 2i - (i & (j-1)) and a + j: for j <= 64 the 64 pairs of one wavefront's iteration stay inside one
+// 128-key span, so those stages need no workgroup barrier (LDS operations of one wave complete in order);
+// only the j >= 128 stages and the hand-over between the two kinds synchronise the workgroup.  The loads
+// of a stage are issued together (four pairs at a time) so that one LDS round trip covers them.
+__device__ __forceinline__ void bitonic_stage(unsigned long long *k, int N, int kk, int j, int tid, int nthreads)
+{
+    for (int i0 = tid; i0 < (N >> 1); i0 += 4 * nthreads) {
+        unsigned long long x[4], y[4];
+        int a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r * nthreads;
+            a[r] = 2 * i - (i & (j - 1));
+            if (i < (N >> 1)) { x[r] = k[a[r]]; y[r] = k[a[r] + j]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r * nthreads;
+            if (i < (N >> 1)) {
+                const bool desc = (a[r] & kk) == 0;
+                if ((x[r] < y[r]) == desc) { k[a[r]] = y[r]; k[a[r] + j] = x[r]; }
+            }
+        }
+    }
+}
 __device__ __forceinline__ void bitonic_sort_desc(unsigned long long *k, int N, int tid, int nthreads)
 {
+    const bool wave_local_ok = (nthreads & 63) == 0;
     for (int kk = 2; kk <= N; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < (N >> 1); i += nthreads) {
-                const int a = 2 * i - (i & (j - 1)), bidx = a + j;
-                const unsigned long long x = k[a], y = k[bidx];
-                const bool desc = (a & kk) == 0;
-                if ((x < y) == desc) { k[a] = y; k[bidx] = x; }
-            }
-            __syncthreads();
+            bitonic_stage(k, N, kk, j, tid, nthreads);
+            if (j > 64 || j == 1 || !wave_local_ok) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
 struct Box { float x1, y1, x2, y2, area; };
+// Keep list of up to `cap` boxes: corners as 16-byte vectors, areas apart (20 bytes a box, both parts
+// naturally aligned so that a box is one 16-byte and one 4-byte load, broadcast when every lane reads the same i).
+struct KeepList {
+    f32x4 *c;
+    float *area;
+    __device__ __forceinline__ KeepList(void *base, int cap) : c((f32x4 *)base), area((float *)((f32x4 *)base + cap)) {}
+    __device__ __forceinline__ Box get(int i) const { const f32x4 v = c[i]; return Box{v[0], v[1], v[2], v[3], area[i]}; }
+    __device__ __forceinline__ void set(int i, const Box &b) const { c[i] = f32x4{b.x1, b.y1, b.x2, b.y2}; area[i] = b.area; }
+};
 __device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2)
 {   // cpu_nms.pyx:24  (x2 - x1 + 1) * (y2 - y1 + 1)
     return __fmul_rn(__fadd_rn(__fsub_rn(x2, x1), 1.f), __fadd_rn(__fsub_rn(y2, y1), 1.f));
 }
-// cpu_nms.pyx:55-65, i = the kept (higher-score) box, j = the candidate
-__device__ __forceinline__ float iou_plus1(const Box &i, const Box &j)
+
+// The suppression test of cpu_nms.pyx:55-66 is  ovr = inter / (area_i + area_j - inter)  in fp32, then
+// ovr >= thresh (thresh a double; nms_kernel.cu:71 has ovr > thresh).  Both reduce to ovr >= b for one
+// fp32 b (make_rule).  (A division-free form -- inter vs m*uni in double, m the rounding midpoint below b --
+// is exact too but measured 15-20 % slower than v_div on gfx950: fp64 converts and compares are not full rate.)
+struct NmsRule { float b; };
+static NmsRule make_rule(double thresh, int strict_gt)
 {
-    const float xx1 = i.x1 >= j.x1 ? i.x1 : j.x1;
-    const float yy1 = i.y1 >= j.y1 ? i.y1 : j.y1;
-    const float xx2 = i.x2 <= j.x2 ? i.x2 : j.x2;
-    const float yy2 = i.y2 <= j.y2 ? i.y2 : j.y2;
-    float w = __fadd_rn(__fsub_rn(xx2, xx1), 1.f);
-    float h = __fadd_rn(__fsub_rn(yy2, yy1), 1.f);
-    w = 0.f >= w ? 0.f : w;
-    h = 0.f >= h ? 0.f : h;
-    const float inter = __fmul_rn(w, h);
-    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(i.area, j.area), inter));
+    float b = (float)thresh;
+    if (strict_gt) {                      // ovr > thresh  <=>  ovr >= succ(largest fp32 <= thresh)
+        if ((double)b > thresh) b = nextafterf(b, -INFINITY);
+        b = nextafterf(b, INFINITY);
+    } else if ((double)b < thresh) {      // (double)ovr >= thresh  <=>  ovr >= smallest fp32 >= thresh
+        b = nextafterf(b, INFINITY);
+    }
+    return NmsRule{b};
 }
-__device__ __forceinline__ bool over(float ovr, float bound, int strict) { return strict ? (ovr > bound) : (ovr >= bound); }
+// i = the kept (higher-score) box, j = the candidate
+__device__ __forceinline__ bool suppresses(const Box &i, const Box &j, const NmsRule &r)
+{
+    const float xx1 = fmaxf(i.x1, j.x1), yy1 = fmaxf(i.y1, j.y1);
+    const float xx2 = fminf(i.x2, j.x2), yy2 = fminf(i.y2, j.y2);
+    const float w = fmaxf(0.f, __fadd_rn(__fsub_rn(xx2, xx1), 1.f));
+    const float h = fmaxf(0.f, __fadd_rn(__fsub_rn(yy2, yy1), 1.f));
+    const float inter = __fmul_rn(w, h);
+    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(i.area, j.area), inter)) >= r.b;
+}
+
+// Box of lane `src` (wave-uniform) broadcast to every lane through v_readlane (no LDS round trip).
+__device__ __forceinline__ Box box_of_lane(const Box &me, int src)
+{
+    Box o;
+    o.x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.x1), src));
+    o.y1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.y1), src));
+    o.x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.x2), src));
+    o.y2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.y2), src));
+    o.area = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(me.area), src));
+    return o;
+}
+// Is the candidate suppressed by any of kept[lo, hi)?  Four boxes per trip so that the (broadcast) LDS
+// reads of a trip overlap; the result equals the one-at-a-time scan's.
+__device__ __forceinline__ bool suppressed_by(const KeepList &kept, int lo, int hi, const Box &me, const NmsRule &r)
+{
+    bool dead = false;
+    int i = lo;
+    for (; i + 4 <= hi && !dead; i += 4) {
+        const Box k0 = kept.get(i), k1 = kept.get(i + 1), k2 = kept.get(i + 2), k3 = kept.get(i + 3);
+        dead = (int)suppresses(k0, me, r) | (int)suppresses(k1, me, r) | (int)suppresses(k2, me, r) | (int)suppresses(k3, me, r);
+    }
+    for (; i < hi && !dead; ++i) dead = suppresses(kept.get(i), me, r);
+    return dead;
+}
+// One wavefront settles 64 candidates (lane = candidate, descending score) of which `alive` survived the
+// boxes kept so far: candidate j is kept iff no kept candidate i < j of the same 64 suppresses it.
+// Returns the keep mask.  Only candidates that are still alive can suppress, so only those are broadcast.
+__device__ __forceinline__ unsigned long long settle64(const Box &me, bool alive, const NmsRule &r)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long amask = __ballot(alive);
+    unsigned long long sup = 0ull;                    // bit i: candidate i (i < lane, alive) overlaps me
+    for (unsigned long long m = amask; m; m &= m - 1ull) {
+        const int i = __builtin_ctzll(m);
+        const Box o = box_of_lane(me, i);
+        if (i < lane && suppresses(o, me, r)) sup |= 1ull << i;
+    }
+    unsigned long long km = 0ull;
+    for (unsigned long long m = amask; m; m &= m - 1ull) {
+        const int i = __builtin_ctzll(m);
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)sup, i);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sup >> 32), i);
+        const unsigned long long s_i = ((unsigned long long)hi << 32) | lo;
+        if ((s_i & km) == 0ull) km |= 1ull << i;
+    }
+    return km;
+}
 
 // One wavefront: greedy NMS over `n` candidates given in descending order.  get(pos, box) loads
-// candidate pos.  kept[] (capacity cap) holds the boxes kept so far; emit(slot, pos) records a
+// candidate pos.  kept (capacity cap) holds the boxes kept so far; emit(slot, pos) records a
 // survivor.  Stops when cap survivors exist (cap = n reproduces the full cpu_nms list).
 template <typename Get, typename Emit>
-__device__ __forceinline__ int wave_greedy_nms(int n, int cap, float bound, int strict, Box *kept, Get get, Emit emit)
+__device__ __forceinline__ int wave_greedy_nms(int n, int cap, const NmsRule &r, const KeepList &kept, Get get, Emit emit)
 {
     const int lane = threadIdx.x & 63;
     int nk = 0;
@@ -147,29 +255,12 @@ __device__ __forceinline__ int wave_greedy_nms(int n, int cap, float bound, int 
         const bool valid = pos < n;
         Box me = {0.f, 0.f, 0.f, 0.f, 1.f};
         if (valid) get(pos, me);
-        bool alive = valid;
-        for (int i = 0; i < nk && alive; ++i)
-            if (over(iou_plus1(kept[i], me), bound, strict)) alive = false;
-        // pairwise suppression inside the chunk: bit i of sup = "candidate i (i < lane) suppresses me"
-        unsigned long long sup = 0ull;
-        for (int i = 0; i < 63; ++i) {
-            Box o;
-            o.x1 = __shfl(me.x1, i, 64); o.y1 = __shfl(me.y1, i, 64);
-            o.x2 = __shfl(me.x2, i, 64); o.y2 = __shfl(me.y2, i, 64); o.area = __shfl(me.area, i, 64);
-            if (i < lane && over(iou_plus1(o, me), bound, strict)) sup |= 1ull << i;
-        }
-        const unsigned long long amask = __ballot(alive);
-        unsigned long long km = 0ull;
-        for (int i = 0; i < 64; ++i) {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)sup, i);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sup >> 32), i);
-            const unsigned long long s_i = ((unsigned long long)hi << 32) | lo;
-            if (((amask >> i) & 1ull) && (s_i & km) == 0ull) km |= 1ull << i;
-        }
+        const bool alive = valid && !suppressed_by(kept, 0, nk, me, r);
+        const unsigned long long km = settle64(me, alive, r);
         const bool keepme = (km >> lane) & 1ull;
         const int slot = nk + __popcll(km & ((1ull << lane) - 1ull));
         if (keepme && slot < cap) {
-            kept[slot] = me;
+            kept.set(slot, me);
             emit(slot, pos);
         }
         nk += __popcll(km);
@@ -179,16 +270,17 @@ __device__ __forceinline__ int wave_greedy_nms(int n, int cap, float bound, int 
     return nk < cap ? nk : cap;
 }
 
-// Workgroup version for Detect (256 threads): candidates are taken 256 at a time; every thread first
-// tests its candidate against the keep list as it stood at the start of the round (the long scan, now
-// spread over 4 waves), then wave 0 resolves the round 64 candidates at a time against only the boxes
-// kept DURING this round plus the pairwise bits.  Same decisions as the sequential algorithm.
+// Workgroup version for Detect (256 threads), resumable: *nk_s boxes are already in `kept` on entry (the
+// caller zeroes it once) and the n candidates given continue the descending order.  Candidates are taken
+// 256 at a time; every thread first tests its candidate against the keep list as it stood at the start of
+// the round (the long scan, spread over 4 waves), then wave 0 settles the round 64 candidates at a time
+// against only the boxes kept DURING this round plus the pairwise bits.  Same decisions as the sequential
+// algorithm.  Returns min(*nk_s, cap).
 template <typename Get, typename Emit>
-__device__ __forceinline__ int block_greedy_nms(int n, int cap, float bound, Box *kept, unsigned char *alive_s, int *nk_s,
-                                                Get get, Emit emit)
+__device__ __forceinline__ int block_greedy_nms(int n, int cap, const NmsRule &r, const KeepList &kept, unsigned char *alive_s,
+                                                int *nk_s, Get get, Emit emit)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) *nk_s = 0;
     __syncthreads();
     for (int c0 = 0; c0 < n; c0 += 256) {
         const int nk0 = *nk_s;
@@ -197,40 +289,27 @@ __device__ __forceinline__ int block_greedy_nms(int n, int cap, float bound, Box
         const bool valid = pos < n;
         Box me = {0.f, 0.f, 0.f, 0.f, 1.f};
         if (valid) get(pos, me);
-        bool alive = valid;
-        for (int i = 0; i < nk0 && alive; ++i)
-            if (over(iou_plus1(kept[i], me), bound, 0)) alive = false;
+        const bool alive = valid && !suppressed_by(kept, 0, nk0, me, r);
         alive_s[tid] = alive ? 1 : 0;
         __syncthreads();
         if (wave == 0) {
             int nk = nk0;
             for (int sub = 0; sub < 4 && nk < cap && c0 + sub * 64 < n; ++sub) {
                 const int p2 = c0 + sub * 64 + lane;
-                const bool v2 = p2 < n;
-                Box b2 = {0.f, 0.f, 0.f, 0.f, 1.f};
-                if (v2) get(p2, b2);
-                bool al = v2 && alive_s[sub * 64 + lane];
-                for (int i = nk0; i < nk && al; ++i)        // boxes kept earlier in this round
-                    if (over(iou_plus1(kept[i], b2), bound, 0)) al = false;
-                unsigned long long sup = 0ull;
-                for (int i = 0; i < 63; ++i) {
-                    Box o;
-                    o.x1 = __shfl(b2.x1, i, 64); o.y1 = __shfl(b2.y1, i, 64);
-                    o.x2 = __shfl(b2.x2, i, 64); o.y2 = __shfl(b2.y2, i, 64); o.area = __shfl(b2.area, i, 64);
-                    if (i < lane && over(iou_plus1(o, b2), bound, 0)) sup |= 1ull << i;
+                Box b2 = me;
+                bool al = alive;
+                if (sub > 0) {
+                    al = p2 < n && alive_s[sub * 64 + lane];
+                    if (__ballot(al) == 0ull) continue;
+                    b2 = Box{0.f, 0.f, 0.f, 0.f, 1.f};
+                    if (al) get(p2, b2);
                 }
-                const unsigned long long amask = __ballot(al);
-                unsigned long long km = 0ull;
-                for (int i = 0; i < 64; ++i) {
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)sup, i);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sup >> 32), i);
-                    const unsigned long long s_i = ((unsigned long long)hi << 32) | lo;
-                    if (((amask >> i) & 1ull) && (s_i & km) == 0ull) km |= 1ull << i;
-                }
+                al = al && !suppressed_by(kept, nk0, nk, b2, r);          // boxes kept earlier in this round
+                const unsigned long long km = settle64(b2, al, r);
                 const bool keepme = (km >> lane) & 1ull;
                 const int slot = nk + __popcll(km & ((1ull << lane) - 1ull));
                 if (keepme && slot < cap) {
-                    kept[slot] = b2;
+                    kept.set(slot, b2);
                     emit(slot, p2);
                 }
                 nk += __popcll(km);
@@ -246,63 +325,45 @@ __device__ __forceinline__ int block_greedy_nms(int n, int cap, float bound, Box
 }
 
 // ---- Detect: one workgroup per (image, class) segment -------------------------------------
-// detection.py:52-63.  The workgroup scans its class column of conf (score > conf_thresh, :53),
-// compacts the candidates into LDS as 64-bit keys (score bits : ~prior index), sorts them and runs the
-// greedy NMS against an LDS-resident keep list.  Two launches: the FAST one holds at most `kcap`
-// (2048) candidates in 16 KB of LDS so that every segment of a batch is resident at once; segments with
-// more candidates raise overflow[seg] and are redone by the second launch with a P-sized key buffer
-// (whose other workgroups exit at once).
-__global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
-                                                         const float *__restrict__ conf, int P, int C, int top_k,
-                                                         float conf_thresh, float bound, int kcap, int pass,
-                                                         int *__restrict__ overflow, float *__restrict__ out,
-                                                         int *__restrict__ counts_out)
+// detection.py:52-63.  Scores are order-preserving 32-bit keys (float bits with the sign trick), 0 = "not a
+// candidate"; a sort key is (score key : ~prior index), so equal scores order by ascending prior index.
+__device__ __forceinline__ unsigned score_key(float s)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
-    unsigned long long *sk = dsm;
-    Box *kept = (Box *)(dsm + kcap);
-    int *cnt = (int *)(kept + top_k);
-    unsigned char *alive_s = (unsigned char *)(cnt + 4);
-    const int seg = blockIdx.x;          // b*C + cl
-    const int cl = seg % C, b = seg / C;
-    if (cl == 0) {
-        if (pass == 0 && counts_out && threadIdx.x == 0) counts_out[seg] = 0;
-        return;
-    }
-    if (pass == 1 && !overflow[seg]) return;
-    if (threadIdx.x == 0) *cnt = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const float *col = conf + (size_t)b * P * C + cl;
-    for (int p0 = 0; p0 < P; p0 += 256) {
-        const int p = p0 + threadIdx.x;
-        const float sc = p < P ? col[(size_t)p * C] : 0.f;
-        const bool pass_thr = p < P && sc > conf_thresh;
-        const unsigned long long m = __ballot(pass_thr);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
-        base = __shfl(base, 0, 64);
-        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pass_thr && idx < kcap)
-            sk[idx] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
-    }
-    __syncthreads();
-    const int n = *cnt;
-    if (pass == 0 && threadIdx.x == 0) overflow[seg] = n > kcap ? 1 : 0;
-    if (n == 0 || n > kcap) {
-        if (n == 0 && counts_out && threadIdx.x == 0) counts_out[seg] = 0;
-        return;
-    }
+    const unsigned u = __float_as_uint(s);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(unsigned k)
+{
+    return __uint_as_float(k ^ (((k >> 31) - 1u) | 0x80000000u));
+}
+
+// Optional phase stamps (builds with -DTDRN_DETECT_TIMING only; read back by scripts/detect_phases.py from
+// the tail of the workspace): 100-MHz wall clock at scan/select/compact/sort/nms/pack boundaries.
+#ifdef TDRN_DETECT_TIMING
+#define DT_STAMP(buf, k)                                          \
+    do {                                                          \
+        __syncthreads();                                          \
+        if (threadIdx.x == 0) (buf)[k] = (long long)wall_clock64(); \
+    } while (0)
+#else
+#define DT_STAMP(buf, k) do { } while (0)
+#endif
+
+// Shared by both Detect kernels: sort the n keys in sk[] and continue the greedy NMS with them; survivors
+// are packed as [score, x1, y1, x2, y2] rows (normalised boxes, detection.py:59-62) as they are kept.
+__device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int top_k, const NmsRule &r, const KeepList &kept,
+                                            unsigned char *alive_s, int *nk_s, const float *__restrict__ sb,
+                                            const float *__restrict__ nb, float *__restrict__ orow, long long *stamps)
+{
+    (void)stamps;
     int N = 64;
     while (N < n) N <<= 1;
     for (int i = n + threadIdx.x; i < N; i += 256) sk[i] = 0ull;
     __syncthreads();
     bitonic_sort_desc(sk, N, threadIdx.x, 256);
-    const float *sb = sboxes + (size_t)b * P * 4;
-    const float *nb = boxes + (size_t)b * P * 4;
-    float *orow = out + (size_t)seg * top_k * 5;
-    const int nk = block_greedy_nms(
-        n, top_k, bound, kept, alive_s, cnt + 1,
+    DT_STAMP(stamps, 4);
+    return block_greedy_nms(
+        n, top_k, r, kept, alive_s, nk_s,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
             const f32x4 v = *(const f32x4 *)(sb + (size_t)p * 4);
@@ -314,9 +375,198 @@ __global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict
             const unsigned p = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
             const f32x4 v = *(const f32x4 *)(nb + (size_t)p * 4);
             float *o = orow + (size_t)slot * 5;
-            o[0] = __uint_as_float((unsigned)(key >> 32));
+            o[0] = key_score((unsigned)(key >> 32));
             o[1] = v[0]; o[2] = v[1]; o[3] = v[2]; o[4] = v[3];
         });
+}
+
+// LDS layout shared by both kernels: sk[kcap] | kept (20 B x top_k) | ctl[16] | alive[256 B] | wsum[8] | (select: hist[256] | sc[P])
+__device__ __forceinline__ void detect_lds(unsigned long long *dsm, int kcap, int top_k, unsigned long long *&sk, void *&kept,
+                                           int *&ctl, unsigned char *&alive_s, int *&wsum, unsigned *&extra)
+{
+    sk = dsm;
+    kept = (void *)(dsm + kcap);
+    ctl = (int *)((char *)kept + (size_t)top_k * sizeof(Box));
+    alive_s = (unsigned char *)(ctl + 16);
+    wsum = (int *)(alive_s + 256);
+    extra = (unsigned *)(wsum + 8);
+}
+static size_t detect_lds_bytes(int kcap, int top_k) { return (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 64 + 256 + 32; }
+
+// Main launch.  The workgroup loads its class row (score > conf_thresh, detection.py:53) into LDS.  Greedy
+// NMS walks candidates in descending score (cpu_nms.pyx:31) and Detect stops at top_k survivors
+// (detection.py:63), so the row is consumed in CHUNKS of at most kcap (2048) candidates: a radix select (8
+// bits a level, most significant first, stopping as soon as a level leaves kcap/2..kcap candidates above a
+// bin boundary) finds a score threshold, the candidates above it and not yet consumed are compacted,
+// sorted, and handed to the resumable NMS.  Every chunk is a contiguous piece of the descending order, so
+// the decisions are the sequential algorithm's.  If more than kcap candidates share one score no threshold
+// separates them: the segment raises overflow[seg] and the second launch redoes it with one full sort.
+__global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
+                                                                const float *__restrict__ scoresT, int P, int C, int top_k,
+                                                                float conf_thresh, NmsRule rule, int kcap,
+                                                                int *__restrict__ overflow, float *__restrict__ out,
+                                                                int *__restrict__ counts_out, long long *__restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
+    long long *stamps = dbg ? dbg + (size_t)blockIdx.x * 8 : nullptr;
+    (void)stamps;
+    DT_STAMP(stamps, 0);
+    unsigned long long *sk; void *kept_mem; int *ctl; unsigned char *alive_s; int *wsum; unsigned *hist;
+    detect_lds(dsm, kcap, top_k, sk, kept_mem, ctl, alive_s, wsum, hist);
+    const KeepList kept(kept_mem, top_k);
+    unsigned *sc = hist + 256;
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // seg = b*C + cl
+    const int cl = seg % C, b = seg / C;
+    float *orow = out + (size_t)seg * top_k * 5;
+    if (tid == 0) overflow[seg] = 0;
+    if (cl == 0) {                                                         // background: detection.py:51 skips it
+        for (int i = tid; i < top_k * 5; i += 256) orow[i] = 0.f;
+        if (counts_out && tid == 0) counts_out[seg] = 0;
+        return;
+    }
+    if (tid < 16) ctl[tid] = tid == 3 ? (int)0xFFFFFFFF : 0;              // [0] n, [1] nk, [2] OR, [3] AND, [4] bin, [5] remaining
+    __syncthreads();
+    // ---- scan: class row -> score keys in LDS (0 = below conf_thresh); loads issued five at a time --------
+    const float *row = scoresT + (size_t)seg * P;
+    int mycnt = 0;
+    unsigned vor = 0u, vand = 0xFFFFFFFFu;
+    for (int p0 = tid; p0 < P; p0 += 5 * 256) {
+        float sv[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) sv[u] = p0 + u * 256 < P ? row[p0 + u * 256] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int p = p0 + u * 256;
+            if (p < P) {
+                const unsigned v = sv[u] > conf_thresh ? score_key(sv[u]) : 0u;
+                sc[p] = v;
+                if (v) { ++mycnt; vor |= v; vand &= v; }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mycnt += __shfl_xor(mycnt, o, 64);
+        vor |= __shfl_xor(vor, o, 64);
+        vand &= __shfl_xor(vand, o, 64);
+    }
+    if (lane == 0) { atomicAdd(&ctl[0], mycnt); atomicOr((unsigned *)&ctl[2], vor); atomicAnd((unsigned *)&ctl[3], vand); }
+    __syncthreads();
+    DT_STAMP(stamps, 1);
+    const int n = ctl[0];
+    if (n == 0) {
+        for (int i = tid; i < top_k * 5; i += 256) orow[i] = 0.f;
+        if (counts_out && tid == 0) counts_out[seg] = 0;
+        return;
+    }
+    // bytes above the highest bit in which two candidates differ are common to all: the select starts below them
+    const unsigned diff = (unsigned)ctl[2] ^ (unsigned)ctl[3];
+    const int shift0 = diff ? ((31 - __clz(diff)) & ~7) : 0;
+    const unsigned mask0 = shift0 < 24 ? 0xFFFFFFFFu << (shift0 + 8) : 0u, prefix0 = (unsigned)ctl[3] & mask0;
+    const int L = ((P + 255) / 256) | 1;                 // compaction: L consecutive scores per thread (odd: conflict-free)
+    const int p_lo = tid * L < P ? tid * L : P, p_hi = p_lo + L < P ? p_lo + L : P;
+    const float *sb = sboxes + (size_t)b * P * 4, *nb = boxes + (size_t)b * P * 4;
+    unsigned hi = 0xFFFFFFFFu;                           // candidates not yet consumed: 0 < key <= hi
+    int taken = 0, nk = 0;
+    for (;;) {
+        // ---- threshold: this chunk = unconsumed candidates with (key & mask) > prefix (mask = 0: all of them) ----
+        unsigned prefix = 0u, mask = 0u;
+        if (n - taken > kcap) {
+            prefix = prefix0;
+            mask = mask0;
+            int remaining = kcap;
+            for (int shift = shift0; shift >= 0; shift -= 8) {
+                hist[tid] = 0u;
+                __syncthreads();
+                for (int p = tid; p < P; p += 256) {
+                    const unsigned v = sc[p];
+                    if (v && v <= hi && (v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                unsigned above = 0u;
+                for (int j = tid + 1; j < 256; ++j) above += hist[j];
+                if ((int)above < remaining && (int)(above + hist[tid]) >= remaining) { ctl[4] = tid; ctl[5] = remaining - (int)above; }
+                __syncthreads();
+                prefix |= (unsigned)ctl[4] << shift;
+                mask |= 0xFFu << shift;
+                remaining = ctl[5];
+                __syncthreads();
+                if (kcap - remaining >= kcap / 2) break;
+            }
+        }
+        DT_STAMP(stamps, 2);
+        // ---- compaction (order is irrelevant, the sort follows): per-thread counts, workgroup scan, scatter ----
+        int c = 0;
+        for (int p = p_lo; p < p_hi; ++p) {
+            const unsigned v = sc[p];
+            c += (v && v <= hi && (mask ? (v & mask) > prefix : true)) ? 1 : 0;
+        }
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int idx = incl - c;
+        for (int w = 0; w < wave; ++w) idx += wsum[w];
+        const int nsel = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (nsel == 0 || nsel > kcap) {                                    // >kcap candidates share one score
+            if (tid == 0) overflow[seg] = 1;
+            return;
+        }
+        for (int p = p_lo; p < p_hi; ++p) {
+            const unsigned v = sc[p];
+            if (v && v <= hi && (mask ? (v & mask) > prefix : true))
+                sk[idx++] = ((unsigned long long)v << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+        }
+        __syncthreads();
+        DT_STAMP(stamps, 3);
+        nk = sort_and_nms(sk, nsel, top_k, rule, kept, alive_s, ctl + 1, sb, nb, orow, stamps);
+        DT_STAMP(stamps, 5);
+        taken += nsel;
+        if (nk >= top_k || taken >= n) break;
+        hi = prefix | ~mask;                                               // what is left lies at or below this chunk's bin
+        __syncthreads();
+    }
+    for (int i = nk * 5 + tid; i < top_k * 5; i += 256) orow[i] = 0.f;      // detection.py:39 zero-initialised output
+    if (counts_out && tid == 0) counts_out[seg] = nk;
+    DT_STAMP(stamps, 6);
+}
+
+// Second launch: segments flagged by the first are redone with every candidate in one sort (P-sized key
+// buffer); all other workgroups exit at once.
+__global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
+                                                         const float *__restrict__ scoresT, int P, int C, int top_k,
+                                                         float conf_thresh, NmsRule rule, int kcap,
+                                                         const int *__restrict__ overflow, float *__restrict__ out,
+                                                         int *__restrict__ counts_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
+    unsigned long long *sk; void *kept_mem; int *ctl; unsigned char *alive_s; int *wsum; unsigned *unused;
+    detect_lds(dsm, kcap, top_k, sk, kept_mem, ctl, alive_s, wsum, unused);
+    const KeepList kept(kept_mem, top_k);
+    const int seg = blockIdx.x;
+    if (!overflow[seg]) return;
+    const int b = seg / C, lane = threadIdx.x & 63;
+    if (threadIdx.x < 2) ctl[threadIdx.x] = 0;
+    __syncthreads();
+    const float *row = scoresT + (size_t)seg * P;
+    for (int p0 = 0; p0 < P; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        const float s = p < P ? row[p] : 0.f;
+        const bool sel = p < P && s > conf_thresh;
+        const unsigned long long m = __ballot(sel);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&ctl[0], __popcll(m));
+        base = __shfl(base, 0, 64);
+        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (sel) sk[idx] = ((unsigned long long)score_key(s) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+    }
+    __syncthreads();
+    float *orow = out + (size_t)seg * top_k * 5;
+    const int nk = sort_and_nms(sk, ctl[0], top_k, rule, kept, alive_s, ctl + 1, sboxes + (size_t)b * P * 4,
+                                boxes + (size_t)b * P * 4, orow, nullptr);
+    for (int i = nk * 5 + threadIdx.x; i < top_k * 5; i += 256) orow[i] = 0.f;
     if (counts_out && threadIdx.x == 0) counts_out[seg] = nk;
 }
 
@@ -324,8 +574,13 @@ static int next_pow2(int v) { int n = 64; while (n < v) n <<= 1; return n; }
 
 size_t detect_workspace_bytes(int B, int P, int C, int top_k)
 {
-    (void)top_k;
-    return align_up((size_t)B * P * 4 * sizeof(float), 256) * 2 + align_up((size_t)B * C * sizeof(int), 256);   // boxes, boxes*scale, overflow flags
+    (void)top_k;   // boxes, boxes*scale, class-major scores, overflow flags
+    size_t n = align_up((size_t)B * P * 4 * sizeof(float), 256) * 2 + align_up((size_t)B * C * P * sizeof(float), 256) +
+               align_up((size_t)B * C * sizeof(int), 256);
+#ifdef TDRN_DETECT_TIMING
+    n += (size_t)B * C * 8 * sizeof(long long);
+#endif
+    return n;
 }
 
 int launch_detect(const float *loc, const float *conf, const float *priors, const float *arm_loc, const float *scale4,
@@ -337,38 +592,43 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
     if (B <= 0 || P <= 0 || C < 2 || top_k <= 0) return TDRN_E_ARG;
     if (ws_bytes < detect_workspace_bytes(B, P, C, top_k)) return TDRN_E_WORKSPACE;
     const int kcap_big = next_pow2(P);
-    const int kcap_fast = kcap_big < 2048 ? kcap_big : 2048;
-    const size_t tail = (size_t)top_k * sizeof(Box) + 32 + 256;      // keep list, counters, alive flags
-    const size_t lds_big = (size_t)kcap_big * 8 + tail, lds_fast = (size_t)kcap_fast * 8 + tail;
-    if (lds_big > 160 * 1024) return TDRN_E_UNSUPPORTED;
+    const int kcap_sel = kcap_big < 2048 ? kcap_big : 2048;
+    const size_t lds_big = detect_lds_bytes(kcap_big, top_k);
+    const size_t lds_sel = detect_lds_bytes(kcap_sel, top_k) + 256 * 4 + (size_t)P * 4;
+    const size_t lds_dec = (size_t)256 * (C | 1) * sizeof(float);
+    if (lds_big > 160 * 1024 || lds_sel > 160 * 1024 || lds_dec > 160 * 1024) return TDRN_E_UNSUPPORTED;
     char *w = (char *)ws;
-    float *boxes = (float *)w;  w += align_up((size_t)B * P * 4 * sizeof(float), 256);
-    float *sboxes = (float *)w; w += align_up((size_t)B * P * 4 * sizeof(float), 256);
-    int *overflow = (int *)w;
-    // (double)ovr >= thresh  <=>  ovr >= bound, bound = smallest fp32 whose double value >= thresh
-    float bound = (float)nms_thresh;
-    if ((double)bound < nms_thresh) bound = nextafterf(bound, INFINITY);
-    TDRN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * C * top_k * 5 * sizeof(float), s));
-    const long long bp = (long long)B * P;
-    hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((bp + 255) / 256)), dim3(256), 0, s, loc, arm_loc, priors, B, P,
-                       f32x4{scale4[0], scale4[1], scale4[2], scale4[3]}, boxes, sboxes);
+    float *boxes = (float *)w;   w += align_up((size_t)B * P * 4 * sizeof(float), 256);
+    float *sboxes = (float *)w;  w += align_up((size_t)B * P * 4 * sizeof(float), 256);
+    float *scoresT = (float *)w; w += align_up((size_t)B * C * P * sizeof(float), 256);
+    int *overflow = (int *)w;    w += align_up((size_t)B * C * sizeof(int), 256);
+    long long *dbg = nullptr;
+#ifdef TDRN_DETECT_TIMING
+    dbg = (long long *)w;
+#endif
+    const NmsRule rule = make_rule(nms_thresh, 0);
     static bool attr_set = false;
     if (!attr_set) {
         TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_select_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_fast, s, boxes, sboxes, conf, P, C, top_k,
-                       conf_thresh, bound, kcap_fast, 0, overflow, out, counts_out);
-    if (kcap_big > kcap_fast)
-        hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_big, s, boxes, sboxes, conf, P, C, top_k,
-                           conf_thresh, bound, kcap_big, 1, overflow, out, counts_out);
+    const long long bp = (long long)B * P;
+    hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((bp + 255) / 256)), dim3(256), lds_dec, s, loc, arm_loc, priors, conf,
+                       B, P, C, f32x4{scale4[0], scale4[1], scale4[2], scale4[3]}, boxes, sboxes, scoresT);
+    hipLaunchKernelGGL(detect_select_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_sel, s, boxes, sboxes, scoresT, P, C,
+                       top_k, conf_thresh, rule, kcap_sel, overflow, out, counts_out, dbg);
+    if (kcap_big > kcap_sel)
+        hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_big, s, boxes, sboxes, scoresT, P, C, top_k,
+                           conf_thresh, rule, kcap_big, overflow, out, counts_out);
     return hip_status(hipGetLastError());
 }
 
 // ---- stand-alone NMS (cpu_nms / gpu_nms twins): one workgroup, keep list in global memory ------
-__global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict__ dets, int n, float bound, int strict,
-                                                        int presorted, int kcap, Box *__restrict__ kept,
-                                                        int *__restrict__ keep_out, int *__restrict__ num_out)
+__global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict__ dets, int n, NmsRule rule, int presorted,
+                                                        void *__restrict__ kept_mem, int *__restrict__ keep_out,
+                                                        int *__restrict__ num_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
     unsigned long long *sk = dsm;
@@ -378,7 +638,7 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict_
         unsigned long long k = 0ull;
         if (i < n) {
             // presorted: keep the caller's order (gpu_nms.pyx:25-28 sorts on the host)
-            const unsigned hi = presorted ? (unsigned)(n - i) : __float_as_uint(dets[(size_t)i * 5 + 4]);
+            const unsigned hi = presorted ? (unsigned)(n - i) : score_key(dets[(size_t)i * 5 + 4]);
             k = ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         }
         sk[i] = k;
@@ -386,8 +646,9 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict_
     __syncthreads();
     if (!presorted) bitonic_sort_desc(sk, N, threadIdx.x, 256);
     if (threadIdx.x >= 64) return;
+    const KeepList kept(kept_mem, n);
     const int nk = wave_greedy_nms(
-        n, n, bound, strict, kept,
+        n, n, rule, kept,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
             const float *d = dets + (size_t)p * 5;
@@ -396,7 +657,6 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict_
         },
         [&](int slot, int pos) { keep_out[slot] = (int)(0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull)); });
     if (threadIdx.x == 0) *num_out = nk;
-    (void)kcap;
 }
 
 size_t nms_workspace_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * sizeof(Box), 256); }
@@ -410,16 +670,13 @@ int launch_nms(const float *dets, int n, double thresh, int strict_gt, int preso
     if (ws_bytes < nms_workspace_bytes(n)) return TDRN_E_WORKSPACE;
     const int kcap = next_pow2(n);
     if ((size_t)kcap * 8 > 128 * 1024) return TDRN_E_UNSUPPORTED;   // n <= 16384
-    float bound = (float)thresh;
-    if (strict_gt) { if ((double)bound > thresh) bound = nextafterf(bound, -INFINITY); }
-    else { if ((double)bound < thresh) bound = nextafterf(bound, INFINITY); }
+    const NmsRule rule = make_rule(thresh, strict_gt);
     static bool attr_set = false;
     if (!attr_set) {
         TDRN_HIP_TRY(hipFuncSetAttribute((const void *)nms_plain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_plain_kernel, dim3(1), dim3(256), (size_t)kcap * 8, s, dets, n, bound, strict_gt, presorted, kcap,
-                       (Box *)ws, keep_out, num_out);
+    hipLaunchKernelGGL(nms_plain_kernel, dim3(1), dim3(256), (size_t)kcap * 8, s, dets, n, rule, presorted, ws, keep_out, num_out);
     return hip_status(hipGetLastError());
 }
 

@@ -191,6 +191,50 @@ def test_detect_full_batch_properties_and_worst_case():
     np.testing.assert_allclose(out, refw, rtol=3e-6, atol=1e-6)
 
 
+def test_detect_selection_fallbacks_match_oracle():
+    """More than 2048 candidates per class, arranged so that the top-2048 prefix cannot finish the job:
+    (a) every box identical -> one survivor, the prefix runs out with candidates left (second launch);
+    (b) all scores equal -> no strict score prefix exists (second launch, ties by ascending prior index);
+    (c) scores in two tight clusters -> the radix select has to descend to the low bytes;
+    (d) P = 16320 (the 512x512 prior count) with every prior a candidate."""
+    P = 6375
+    pri = PriorBox(mb_cfg["VOC_320"]).forward()
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    sc = [500.0, 375.0, 500.0, 375.0]
+    rng = np.random.Generator(np.random.PCG64(77))
+    prin = pri.numpy()
+    # (a) loc that maps every prior onto the same box (cx=cy=.5, w=h=.3): invert decode()
+    loc = np.empty((1, P, 4), np.float32)
+    loc[0, :, 0] = (0.5 - prin[:, 0]) / (0.1 * prin[:, 2])
+    loc[0, :, 1] = (0.5 - prin[:, 1]) / (0.1 * prin[:, 3])
+    loc[0, :, 2] = np.log(0.3 / prin[:, 2]) / 0.2
+    loc[0, :, 3] = np.log(0.3 / prin[:, 3]) / 0.2
+    conf = (0.02 + 0.9 * rng.random((P, 21))).astype(np.float32)
+    out = det.forward(_cu(loc), _cu(conf), pri.to(DEV), scale=sc).cpu().numpy()
+    ref = orc.detect(loc, conf, prin, None, sc)
+    assert np.array_equal(out[..., 0], ref[..., 0])
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+    assert (det.last_counts.cpu().numpy()[0, 1:] <= 3).all()
+    # (b) + (c) on spread-out boxes
+    loc2, arm2, _ = synth.synth_detect_inputs(1, P, 21, 8.0, seed=5)
+    confb = np.full((P, 21), 0.04, np.float32)
+    confc = np.where(rng.random((P, 21)) < 0.5, 0.04, 0.0400001).astype(np.float32) + (rng.integers(0, 64, (P, 21)) * 2.0 ** -30).astype(np.float32)
+    for cf in (confb, confc):
+        out = det.forward(_cu(loc2), _cu(cf), pri.to(DEV), arm_loc_data=_cu(arm2), scale=sc).cpu().numpy()
+        ref = orc.detect(loc2, cf, prin, arm2, sc)
+        assert np.array_equal(out[..., 0], ref[..., 0])
+        np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+    # (d)
+    pri5 = PriorBox(mb_cfg["VOC_512_RefineDet"]).forward()
+    P5 = pri5.shape[0]
+    loc5, arm5, _ = synth.synth_detect_inputs(1, P5, 21, 8.0, seed=6)
+    conf5 = (np.full((P5, 21), 1.0 / 21, np.float32) + _rand((P5, 21), 11, 1e-3)).astype(np.float32)
+    out = det.forward(_cu(loc5), _cu(conf5), pri5.to(DEV), arm_loc_data=_cu(arm5), scale=sc).cpu().numpy()
+    ref = orc.detect(loc5, conf5, pri5.numpy(), arm5, sc)
+    assert np.array_equal(out[..., 0], ref[..., 0])
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+
+
 def test_detect_empty_and_errors():
     P = 6375
     pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
