@@ -76,10 +76,170 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// First conv on the matrix cores, exact fp32: D[cout][pixel] = sum_k W[cout][k] X[k][pixel], k = (c, dy, dx)
+// (27 -> 28) with v_mfma_f32_32x32x2_f32 -- 14 instructions per 32 couts x 32 pixels, 64 cycles each, so the
+// layer is paced by the matrix pipe (~80 us at B = 32, 320x320) instead of the vector ALU (1728 FMAs a
+// pixel, ~235 us) and sits beside its 0.42 GB of NHWC output writes.  A workgroup (4 waves) takes tiles
+// of 8 output rows x 32 columns: the fp32 halo tile is staged in LDS (zero padding materialised there),
+// each wave multiplies two rows, and the result leaves through a per-wave LDS transpose as whole
+// 128-byte NHWC lines.  Weights (one value per lane per instruction) stay in registers across tiles.
+// Couts beyond Cout (channel padding) are written as zeros.  Requires Cpad == 64 and stride 1 or 2.
+// ---------------------------------------------------------------------------------------------
+template <typename DT, int STRIDE>
+__global__ __launch_bounds__(256) void first_conv_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, char *__restrict__ out,
+                                                              int B, int S, int So, int Cout, int relu, int tiles_x, int tiles_y)
+{
+    constexpr int ES = elem_traits<DT>::bytes;
+    constexpr int TR = 8, TC = 32;                       // output tile
+    constexpr int IH = (TR - 1) * STRIDE + 3, IW = (TC - 1) * STRIDE + 3;   // halo tile
+    constexpr int NIN = 3 * IH * IW, NE = (NIN + 255) / 256;
+    constexpr int TS = 64 * ES + 16;                     // staging row stride (one pixel = 64 couts)
+    __shared__ __attribute__((aligned(16))) float xin[NIN];
+    __shared__ __attribute__((aligned(16))) char stage[4 * 32 * TS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r32 = lane & 31, hh = lane >> 5;
+
+    // A operand: lane (r32, hh) holds W[32*ci + r32][2*s + hh]; B operand: X[2*s + hh][pixel r32]
+    float wr[2][14];
+    int koff[14];                                        // LDS offset of my k of step s, relative to the pixel's halo origin
+#pragma unroll
+    for (int s2 = 0; s2 < 14; ++s2) {
+        const int k = 2 * s2 + hh;
+        const int c = k / 9, r = (k - 9 * c) / 3, q = k - 9 * c - 3 * r;
+        koff[s2] = k < 27 ? (c * IH + r) * IW + q : 0;   // k = 27 is the zero pad of K: its weight is 0
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+            const int co = ci * 32 + r32;
+            wr[ci][s2] = (k < 27 && co < Cout) ? w[co * 27 + k] : 0.f;
+        }
+    }
+    float bq[2][4][4];                                   // bias of my accumulator rows: cout = 32*ci + 8*g + 4*hh + j
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = ci * 32 + 8 * g + 4 * hh + j;
+                bq[ci][g][j] = co < Cout ? bias[co] : 0.f;
+            }
+    char *stg = stage + wave * 32 * TS;
+    constexpr int CPR = 64 * ES / 16;                    // 16-B chunks per pixel
+    constexpr int RPI = 64 / CPR;                        // pixels per wave store instruction
+    const int my_ch = lane % CPR, my_row = lane / CPR;
+
+    // halo elements e*256 + t of a tile: plane/row/col are tile-independent (compile-time divisors)
+    int e_rq[NE], e_off[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = e * 256 + t;
+        const int c = i / (IH * IW), rem = i - c * (IH * IW);
+        const int r = rem / IW, q = rem - r * IW;
+        e_rq[e] = i < NIN ? ((r << 16) | q) : -1;
+        e_off[e] = (c * S + r) * S + q;
+    }
+    const int n_tiles = B * tiles_y * tiles_x;
+    float pre[NE];
+    auto fetch = [&](int tile) {                         // halo of `tile` -> registers (zero padding applied here)
+        const int b = tile / (tiles_y * tiles_x), tt = tile - b * tiles_y * tiles_x;
+        const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int iy0 = ty * TR * STRIDE - 1, ix0 = tx * TC * STRIDE - 1;
+        const float *xb = x + (size_t)b * 3 * S * S + (long long)iy0 * S + ix0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int yy = iy0 + (e_rq[e] >> 16), xx = ix0 + (e_rq[e] & 0xffff);
+            const bool ok = e_rq[e] >= 0 && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S;
+            pre[e] = ok ? xb[e_off[e]] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / (tiles_y * tiles_x), tt = tile - b * tiles_y * tiles_x;
+        const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+        const int oy0 = ty * TR, ox0 = tx * TC;
+        __syncthreads();                                 // the previous tile's reads of xin are done
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (e * 256 + t < NIN) xin[e * 256 + t] = pre[e];
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);       // lands while this tile multiplies
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int orow = 2 * wave + rr;              // tile-local output row of this pass
+            const int oy = oy0 + orow;
+            if (oy >= So) break;                         // wave-uniform
+            f32x16 acc[2];
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ci][4 * g + j] = bq[ci][g][j];
+            const int porg = (orow * STRIDE) * IW + r32 * STRIDE;      // halo origin of my pixel
+            float xv[14];
+#pragma unroll
+            for (int s2 = 0; s2 < 14; ++s2) xv[s2] = xin[porg + koff[s2]];
+#pragma unroll
+            for (int s2 = 0; s2 < 14; ++s2)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+                    acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[ci][s2], xv[s2], acc[ci], 0, 0, 0);
+            // ---- ReLU, convert, transpose through LDS, whole-line stores ----
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float q4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q4[j] = relu ? fmaxf(acc[ci][4 * g + j], 0.f) : acc[ci][4 * g + j];
+                    char *d = stg + r32 * TS + (ci * 32 + 8 * g + 4 * hh) * ES;
+                    if constexpr (ES == 4) {
+                        *(f32x4 *)d = f32x4{q4[0], q4[1], q4[2], q4[3]};
+                    } else {
+                        *(uint2 *)d = make_uint2((unsigned)from_f32<DT>(q4[0]).v | ((unsigned)from_f32<DT>(q4[1]).v << 16),
+                                                 (unsigned)from_f32<DT>(q4[2]).v | ((unsigned)from_f32<DT>(q4[3]).v << 16));
+                    }
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): my LDS writes are done
+            __builtin_amdgcn_wave_barrier();
+            const size_t prow = ((size_t)b * So + oy) * So + ox0;
+#pragma unroll
+            for (int k = 0; k < 32 / RPI; ++k) {
+                const int px = my_row + k * RPI;
+                if (ox0 + px < So)
+                    *(u32x4 *)(out + (prow + px) * 64 * ES + my_ch * 16) = *(const u32x4 *)(stg + px * TS + my_ch * 16);
+            }
+            __builtin_amdgcn_wave_barrier();             // (a wave's DS instructions execute in order)
+        }
+    }
+}
+
 int launch_first_conv(const float *x, const float *w, const float *bias, void *out, int B, int S, int stride,
                       int Cout, int Cpad, int relu, int dtype, hipStream_t s)
 {
     const int So = (S + 2 - 3) / stride + 1;
+    static int use_mfma = -1;
+    if (use_mfma < 0) { const char *e = getenv("TDRN_FIRST_MFMA"); use_mfma = e ? atoi(e) : 1; }
+    if (use_mfma && Cpad == 64 && (stride == 1 || stride == 2)) {
+        const int tiles_x = (So + 31) / 32, tiles_y = (So + 7) / 8;
+        const long long n_tiles = (long long)B * tiles_x * tiles_y;
+#define LM(DT)                                                                                                              \
+    do {                                                                                                                    \
+        auto k1 = first_conv_mfma_kernel<DT, 1>;                                                                            \
+        auto k2 = first_conv_mfma_kernel<DT, 2>;                                                                            \
+        static int fit[2] = {0, 0};   /* persistent grid = what fits at once (register-limited: 3-4 workgroups per CU) */   \
+        int &per_cu = fit[stride - 1];                                                                                      \
+        if (per_cu == 0) TDRN_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stride == 1 ? k1 : k2, 256, 0)); \
+        const long long cap = 256ll * (per_cu > 0 ? per_cu : 1);                                                            \
+        dim3 grid((unsigned)(n_tiles < cap ? n_tiles : cap));                                                               \
+        if (stride == 1) hipLaunchKernelGGL(k1, grid, dim3(256), 0, s, x, w, bias, (char *)out, B, S, So, Cout, relu, tiles_x, tiles_y); \
+        else hipLaunchKernelGGL(k2, grid, dim3(256), 0, s, x, w, bias, (char *)out, B, S, So, Cout, relu, tiles_x, tiles_y);             \
+    } while (0)
+        if (dtype == TDRN_F32) LM(float); else if (dtype == TDRN_BF16) LM(bf16_t); else LM(f16_t);
+#undef LM
+        return hip_status(hipGetLastError());
+    }
     const long long total = (long long)B * So * So;
     dim3 grid((unsigned)((total + 255) / 256));
 #define L(DT) hipLaunchKernelGGL((first_conv_kernel<DT>), grid, dim3(256), 0, s, x, w, bias, (char *)out, B, S, So, stride, Cout, Cpad, relu)
