@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
-    ap.add_argument("--cpu-frames", type=int, default=48)
+    ap.add_argument("--cpu-frames", type=int, default=96)      # ~16 s of CPU work on the GPU box host
     args = ap.parse_args()
 
     import torch

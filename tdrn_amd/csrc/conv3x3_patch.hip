@@ -611,7 +611,12 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
         p.tiles_x = 0; p.tiles_per_img = 0;
         p.m_tiles = cdiv(p.M, 256);
     }
-    const int BN = a.Npad % 128 == 0 ? 128 : 64;
+    // 128-cout items unless they would leave most CUs idle (20x20 maps at small batch): 64-cout items double
+    // the item count for the same per-output arithmetic (K order unchanged, results identical)
+    static int small_bn = -1;
+    if (small_bn < 0) { const char *e = getenv("TDRN_PATCH_SMALL_BN"); small_bn = e ? atoi(e) : 1; }
+    int BN = a.Npad % 128 == 0 ? 128 : 64;
+    if (small_bn && BN == 128 && p.m_tiles * (a.Npad / 128) < 160) BN = 64;
     p.n_tiles = a.Npad / BN;
     p.items = p.m_tiles * p.n_tiles;
     static int ablate = -1;
