@@ -89,6 +89,16 @@ def lib():
             raise ImportError(
                 "libtdrn_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C tdrn_amd/csrc`.  tdrn_amd has no CPU fallback." % LIB_PATH)
+        # Load order matters on a GPU box: the library registers its code objects with the HIP runtime when it is
+        # mapped, and if that happens before PyTorch has brought the runtime up, every later HIP call from the
+        # library fails with hipErrorNoDevice (seen with build() followed by smoke() in one process).  So let
+        # torch initialise the device first whenever one is visible (a no-op in the GPU-less build container).
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)           # AttributeError if the ABI lost a symbol
