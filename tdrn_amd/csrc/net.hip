@@ -91,6 +91,7 @@ struct tdrn_net {
     size_t splitk_off[kLanes] = {0, 0, 0, 0};   // per-lane split-K slab region (bytes per sample from workspace start)
     int cur_lane = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
+    int plan_error = TDRN_OK;
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
@@ -300,6 +301,10 @@ struct tdrn_net {
     {
         const Tensor ti = tensors[in];
         const int nc3 = 3 * cfg.num_classes;
+        // shape_check, deform_conv_cuda.c:75-76 "input image is smaller than kernel": the reference throws when a
+        // 5x5 multihead branch meets the 3x3 map of a 192-pixel frame
+        const int kmax = loc2.empty() ? 3 : 5;
+        if (ti.H < kmax || ti.W < kmax) plan_error = TDRN_E_SHAPE;
         Op o; o.kind = OP_DEFORM; o.stat = ST_DEFORM; o.in = in; o.off_t = off_t; o.scale = scale; o.G = G;
         o.Cin = ti.Cpad; o.Cout = 12 + nc3; o.Npad = deform_n_pad(o.Cout);
         o.k = 3; o.pad = 1; o.w = loc1; o.b = conf1; o.out_kind = out_loc_kind;
@@ -552,7 +557,9 @@ struct tdrn_net {
     int build()
     {
         es = dtype_bytes(cfg.dtype);
-        if (cfg.size != 320 && cfg.size != 512) return TDRN_E_ARG;
+        // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
+        // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
+        if (cfg.size < 128 || cfg.size > 1280 || cfg.size % 64 != 0) return TDRN_E_ARG;
         if (cfg.num_classes < 2 || cfg.num_classes > 21 * 4) return TDRN_E_ARG;
         if (cfg.dtype < 0 || cfg.dtype > 2) return TDRN_E_ARG;
         if (cfg.def_groups < 1) return TDRN_E_ARG;
@@ -566,6 +573,7 @@ struct tdrn_net {
             default: return TDRN_E_UNSUPPORTED;
         }
         if (rc != TDRN_OK) return rc;
+        if (plan_error != TDRN_OK) return plan_error;
         // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
         {

@@ -4,7 +4,7 @@ import ctypes as C
 import torch
 
 from .. import _lib
-from .config import mb_cfg, VOC_320, VOC_512_RefineDet   # noqa: F401
+from .config import mb_cfg, multi_cfg, multi_cfg_512, VOC_320, VOC_512_RefineDet   # noqa: F401
 
 MEANS = (104, 117, 123)   # BGR order, like every driver of the reference (evaluate.py:83, test_video.py:36)
 

@@ -14,6 +14,7 @@ class EngineModule(nn.Module):
 
     def _engine_init(self, **kwargs):
         object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_size_engines", {})
         object.__setattr__(self, "_engine_args", kwargs)
         object.__setattr__(self, "_dirty", True)
         object.__setattr__(self, "compute_dtype", os.environ.get("TDRN_DTYPE", "fp32"))
@@ -22,6 +23,7 @@ class EngineModule(nn.Module):
     def set_compute_dtype(self, name):
         object.__setattr__(self, "compute_dtype", name)
         object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_size_engines", {})
         object.__setattr__(self, "_dirty", True)
         return self
 
@@ -63,7 +65,26 @@ class EngineModule(nn.Module):
         if self._dirty or self._engine.device != torch.device(device):
             self._engine.load(super().state_dict(), device)
             object.__setattr__(self, "_dirty", False)
+            object.__setattr__(self, "_size_engines", {})        # they share the blob that was just replaced
         return self._engine
+
+    def engine_for(self, x):
+        """The engine that runs input x.  The reference nets are fully convolutional: multi_eval.py:526-547
+        feeds one net frames of 192..704 (1216) pixels.  The plan of a tdrn_net is static per input size, so
+        every other size gets its own plan -- built on first use -- over the SAME packed weight blob."""
+        main = self.engine(x.device)
+        size = int(x.size(-1))
+        if size == self._engine_args["size"]:
+            return main
+        eng = self._size_engines.get(size)
+        if eng is None:
+            args = dict(self._engine_args)
+            args["dtype"] = self.compute_dtype
+            args["size"] = size
+            eng = NetEngine(**args)
+            eng.share_weights(main)
+            self._size_engines[size] = eng
+        return eng
 
     def adopt_broadcast_weights(self, src=0, device=None):
         """Multi-GPU start-up: rank `src` packs, everyone receives the blob by one RCCL broadcast."""

@@ -29,7 +29,7 @@ class RefineSSD(EngineModule):
                           multihead=multihead, test_phase=(phase == 'test'))
 
     def forward(self, x):
-        r = self.engine(x.device).forward(x)
+        r = self.engine_for(x).forward(x)
         conf = r["conf"] if self.phase == 'test' else r["conf"].view(x.size(0), -1, self.num_classes)
         return (r["arm_loc"], None, r["odm_loc"], conf)
 

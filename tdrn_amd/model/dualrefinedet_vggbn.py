@@ -57,7 +57,7 @@ class RefineSSD(EngineModule):
                           def_groups=def_groups, bn=bn, multihead=multihead, test_phase=(phase == 'test'))
 
     def forward(self, x):
-        r = self.engine(x.device).forward(x, want_offsets=True)
+        r = self.engine_for(x).forward(x, want_offsets=True)
         conf = r["conf"] if self.phase == 'test' else r["conf"].view(x.size(0), -1, self.num_classes)
         return (r["arm_loc"], r["offsets"] if self.phase == 'test' else None, r["odm_loc"], conf)
 

@@ -39,7 +39,7 @@ class SSD4Scale_MobNet(EngineModule):
             ref_loc = getattr(offset_list, "ref_loc", None)
             if ref_loc is None:
                 raise ValueError("deform=True needs ref_loc (or an offset_list returned by this net)")
-        r = self.engine(x.device).forward(x, want_offsets=bool(ret_off and self.deform),
+        r = self.engine_for(x).forward(x, want_offsets=bool(ret_off and self.deform),
                                           ref_loc=ref_loc if self.deform else None,
                                           want_loc_maps=bool(ret_loc and not self.deform))
         conf = r["conf"] if self.phase == 'test' else r["conf"].view(x.size(0), -1, self.num_classes)

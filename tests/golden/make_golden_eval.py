@@ -175,6 +175,22 @@ def main():
             for b, s in zip(boxes_np, d[:, 0]):
                 exec(stmt, dict(det_list=det_list, img_id=100 + i, label_map=label_map, j=j, b=b, s=s))
     out["coco"] = {"label_map": {str(k): v for k, v in label_map.items()}, "entries": det_list}
+    # bbox_vote (multi_eval.py:453-494) on clustered boxes: several near-duplicates per object plus singletons
+    nv = reference_functions(os.path.join(REF, "multi_eval.py"), {"bbox_vote"}, dict(np=np))
+    out["bbox_vote"] = []
+    for case in range(5):
+        n_obj = int(rng.integers(1, 6))
+        rows = []
+        for _ in range(n_obj):
+            x1, y1 = rng.uniform(0, 300), rng.uniform(0, 200)
+            bw, bh = rng.uniform(20, 150), rng.uniform(20, 120)
+            for _ in range(int(rng.integers(1, 6))):
+                j = rng.normal(0, 4, 4)
+                rows.append([x1 + j[0], y1 + j[1], x1 + bw + j[2], y1 + bh + j[3], rng.uniform(0.05, 0.99)])
+        det = np.asarray(rows, np.float32)
+        if case == 4:
+            det = det[:1]
+        out["bbox_vote"].append({"det": det.tolist(), "voted": np.asarray(nv["bbox_vote"](det.copy()), np.float64).tolist()})
     json.dump(out, open(os.path.join(HERE, "eval_formats.json"), "w"))
     print("wrote eval_formats.json: %d result lines, %d coco entries" % (sum(len(v.splitlines()) for v in out["result_files"].values()), len(det_list)))
 

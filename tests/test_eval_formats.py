@@ -108,3 +108,33 @@ def test_coco_entries_match_reference(g, tmp_path):
     out = os.path.join(str(tmp_path), "res.json")
     ev.write_coco_results(got, out)
     assert json.load(open(out)) == g["coco"]["entries"]
+
+
+def test_bbox_vote_matches_reference(g):
+    for case in g["bbox_vote"]:
+        det = np.asarray(case["det"], np.float32)
+        got = np.asarray(ev.bbox_vote(det.copy()), np.float64)
+        ref = np.asarray(case["voted"], np.float64).reshape(got.shape)
+        assert np.array_equal(got, ref)
+
+
+def test_merge_detections_unflips_scales_and_filters():
+    """multi_eval.py:553-631 on a hand-made pair of views: the flipped view's box maps back onto the plain
+    one, the 192-pixel scale drops boxes whose longer side is <= 32 px, and the duplicates are voted."""
+    C, K = 3, 4
+    plain = np.zeros((1, C, K, 5), np.float32)
+    flipped = np.zeros((1, C, K, 5), np.float32)
+    small = np.zeros((1, C, K, 5), np.float32)
+    plain[0, 1, 0] = [0.9, 0.10, 0.20, 0.50, 0.60]
+    flipped[0, 1, 0] = [0.7, 0.50, 0.20, 0.90, 0.60]                       # the same box seen mirrored
+    small[0, 1, 0] = [0.8, 0.10, 0.10, 0.15, 0.15]                         # 20 x 15 px at 400 x 300: dropped at 192
+    small[0, 2, 0] = [0.6, 0.10, 0.10, 0.60, 0.70]
+    multi = {"320_320_0": plain, "320_320_1": flipped, "320_192_0": small}
+    out = ev.merge_detections(multi, 400, 300, 320, C)
+    assert sorted(out) == [1, 2]
+    box = out[1]
+    assert box.shape == (1, 5) and box[0, 4] == np.float32(0.9)
+    np.testing.assert_allclose(box[0, :4], [40.0, 60.0, 200.0, 180.0], atol=1e-3)
+    np.testing.assert_allclose(out[2][0], [40.0, 30.0, 240.0, 210.0, 0.6], atol=1e-4)
+    assert ev.scale_filter(320, 704, np.zeros((1, 4), np.float32)) is None     # no branch in the reference
+    assert list(ev.scale_filter(512, 1216, np.array([[0, 0, 10, 10], [0, 0, 100, 100]], np.float32))) == [0]

@@ -8,6 +8,7 @@ import torch
 
 from oracle import net_ref
 from oracle import oracle as orc
+from tdrn_amd import _lib
 from tdrn_amd.data import mb_cfg
 from tdrn_amd.layers import Detect, PriorBox
 from tdrn_amd.utils import synth
@@ -300,3 +301,49 @@ def test_trn_driver_key_frame_protocol():
     assert torch.equal(outs[5], det.forward(t5[0], t5[1], pri, arm_loc_data=s4[0]))
     drv.step(clip[0:1], video_name="v1")            # a new video forces a key frame
     assert drv.key_frames == 3 and drv.current_i == 1
+
+
+@pytest.mark.parametrize("size,mh", [(192, False), (384, True)])
+def test_net_runs_other_input_sizes_like_the_reference(size, mh):
+    """multi_eval.py:526-547 feeds a 320-net frames of 192..704 pixels (the nets are fully convolutional): a
+    second plan over the SAME packed weights, fp32 parity with the oracle at that size."""
+    net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, mh))
+    x = synth.synth_frames(1, size, seed=17)
+    r_arm, r_off, r_odm, r_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, mh)
+    net(torch.from_numpy(synth.synth_frames(1, 320, seed=17)).to(DEV))      # the 320 plan packs the weights
+    arm, offs, odm, conf = net(torch.from_numpy(x).to(DEV))
+    P = 3 * sum((size // s) ** 2 for s in (8, 16, 32, 64))
+    assert arm.shape == (1, P, 4) and conf.shape == (P, 21)
+    assert net.engine_for(torch.from_numpy(x).to(DEV)).weights.data_ptr() == net._engine.weights.data_ptr()
+    np.testing.assert_allclose(arm.cpu().numpy(), r_arm.numpy(), atol=1e-3, rtol=0)
+    for a, b in zip(offs, r_off):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-3, rtol=0)
+    _close_mod_border_flips(odm.cpu().numpy(), r_odm.numpy())
+    _close_mod_border_flips(conf.cpu().numpy(), r_conf.numpy())
+    if size == 384:
+        # shape_check "input image is smaller than kernel" (deform_conv_cuda.c:75): 5x5 heads on the 3x3 map of 192
+        with pytest.raises(_lib.TdrnError):
+            net(torch.from_numpy(synth.synth_frames(1, 192, seed=17)).to(DEV))
+
+
+def test_multi_scale_flip_tester():
+    """multi_eval.py:513-631 end to end on the device for scales 192 + 320 of a 320-net: the un-flipped 320 view
+    is exactly the plain pipeline, every view fills its key, and the merged result is bbox_vote of the parts."""
+    from tdrn_amd.data import base_transform, multi_cfg, MEANS
+    from tdrn_amd.eval import MultiScaleTester, merge_detections
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, False))
+    rng = np.random.Generator(np.random.PCG64(9))
+    frame = torch.from_numpy(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)).to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    pri = {s: PriorBox(multi_cfg[str(s)]).forward().to(DEV) for s in (192, 320)}
+    tester = MultiScaleTester(net, det, pri, ssd_dim=320, mean=MEANS, scales=[192, 320])
+    voted, multi = tester.detect(frame)
+    assert sorted(multi) == ["320_192_0", "320_192_1", "320_320_0", "320_320_1"]
+    assert all(v.shape == (1, 21, 200, 5) for v in multi.values())
+    arm, _, odm, conf = net(base_transform(frame, 320, MEANS, True))
+    plain = det.forward(odm, conf, pri[320], arm_loc_data=arm).cpu().numpy()
+    assert np.array_equal(multi["320_320_0"], plain)
+    again = merge_detections(multi, 400, 300, 320, 21)
+    assert sorted(voted) == sorted(again) and all(np.array_equal(voted[j], again[j]) for j in voted)
+    for j, boxes in voted.items():
+        assert boxes.shape[1] == 5 and (boxes[:, 4] > 0).all()
