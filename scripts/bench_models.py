@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--per-op", default="", help="module name: print that model's per-launch timings")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for mod, a, kw, B in CASES:
@@ -43,6 +44,15 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         print("%-26s %4d px  batch %3d  %s  %8.1f frames/s  %7.3f ms/batch" % (mod, a[0], B, args.dtype, B / dt, dt * 1e3))
+        if args.per_op == mod:
+            eng = net._engine
+            eng.set_profile(True)
+            net(x); net(x)
+            torch.cuda.synchronize()
+            for o in eng.op_stats():
+                tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
+                print("    %-44s %8.1f us %8.1f GF %7.1f TF/s %7.2f GB %7.0f GB/s" % (o["name"], o["ms"] * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9, o["bytes"] / 1e9 / (o["ms"] * 1e-3) if o["ms"] > 0 else 0))
+            eng.set_profile(False)
 
 
 if __name__ == "__main__":
