@@ -75,7 +75,10 @@ class EngineModule(nn.Module):
         main = self.engine(x.device)
         size = int(x.size(-1))
         if size == self._engine_args["size"]:
-            return main
+            return main                                 # (its forward checks the full shape)
+        if x.dim() != 4 or x.size(1) != 3 or x.size(2) != size or size % 64 or not 128 <= size <= 1280:
+            raise ValueError("expected input (B,3,S,S) with S = %d or another multiple of 64 in [128, 1280], got %r"
+                             % (self._engine_args["size"], tuple(x.shape)))
         eng = self._size_engines.get(size)
         if eng is None:
             args = dict(self._engine_args)
