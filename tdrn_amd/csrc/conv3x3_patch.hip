@@ -33,6 +33,10 @@
 // diagnostics build switch (never set in the product build): 1 = loaders issue nothing, 2 = consumers
 // skip ds_read + MFMA, 4 = skip the epilogue stores.  Compile-time on purpose: a runtime flag splits
 // the K loop into basic blocks and hipcc then waits lgkmcnt(0/1) where lgkmcnt(4) would do.
+#ifndef TDRN_PATCH_PRIO
+#define TDRN_PATCH_PRIO 4     // 0: s_setprio 1 around every MFMA group (measured 10 % SLOWER: per-segment flips hurt), 1: none,
+                              // 2/3: static consumer priorities (= none), 4: loaders at static priority 2 (another -3 %), 5: 3
+#endif
 #ifndef TDRN_PATCH_ABLATE
 #define TDRN_PATCH_ABLATE 0
 #endif
@@ -135,6 +139,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 
     if (wave >= 8) {
         // =========================== LOADER ===========================
+        // the loaders' few instructions per step gate everyone's barrier: let them issue ahead of the consumers
+        if (TDRN_PATCH_PRIO == 4) __builtin_amdgcn_s_setprio(2);
+        if (TDRN_PATCH_PRIO == 5) __builtin_amdgcn_s_setprio(3);
         const int lw = wave - 8;
         const int lrow = lane >> 3, pc = lane & 7;
         unsigned poff[kSlotsPerLoader];                 // byte offset of my 16 B in the tensor, or ~0u
@@ -499,6 +506,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     };
 
     __builtin_amdgcn_s_barrier();                       // prologue operands landed
+    if (TDRN_PATCH_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // static: the younger half
+    if (TDRN_PATCH_PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // static: all consumers over the loaders
     if (n_it > 0) {
         setup_item(0);
         init_acc(0);
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             m0 = ((tapmask[0] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
             m1 = ((tapmask[1] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
         }
-        __builtin_amdgcn_s_setprio(1);
+        if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(1);
         load_frags(wfB, pfB, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma_frags(wfA, pfA, m0, m1);
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         load_frags(wfB, pfB, 3);
         __builtin_amdgcn_sched_barrier(0);
         mma_frags(wfA, pfA, m0, m1);
-        __builtin_amdgcn_s_setprio(0);
+        if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(0);
         // every LDS read of this step has returned -> the step's buffers may be refilled after the barrier
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
@@ -550,9 +559,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         }
         load_frags(wfA, pfA, 0);     // (past the last step this reads stale but in-bounds LDS; unused)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(1);
         mma_frags(wfB, pfB, m0, m1);
-        __builtin_amdgcn_s_setprio(0);
+        if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(0);
         if (item_done) {
             epilogue();
             ++it;

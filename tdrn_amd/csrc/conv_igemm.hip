@@ -19,6 +19,9 @@
 
 #include "kernels.h"
 
+#ifndef TDRN_IGEMM_PRIO
+#define TDRN_IGEMM_PRIO 0
+#endif
 namespace tdrn {
 
 struct ConvParams {
@@ -223,9 +226,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
                 advance();
                 stage(nxt);
             }
+#if TDRN_IGEMM_PRIO
             __builtin_amdgcn_s_setprio(1);
+#endif
             compute(cur);
+#if TDRN_IGEMM_PRIO
             __builtin_amdgcn_s_setprio(0);
+#endif
             cur = cur + 1 == STAGES ? 0 : cur + 1;
             nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
