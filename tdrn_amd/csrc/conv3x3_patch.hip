@@ -92,13 +92,24 @@ __device__ __forceinline__ void wait_vmcnt(int n)   // n is wave-uniform
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
     }
 }
 
-constexpr int kPatchSlots = 44;                 // 8-row LDS-DMA pieces per patch buffer (352 rows)
+#ifndef TDRN_PATCH_RING
+#define TDRN_PATCH_RING 3
+#endif
+constexpr int kRing = TDRN_PATCH_RING;          // weight ring depth for the 128-cout kernels: weights go kRing-1 steps ahead
+constexpr int kPatchSlots = kRing == 4 ? 43 : 44;   // 8-row LDS-DMA pieces per patch buffer (344 / 352 rows)
 constexpr int kPatchBytes = kPatchSlots * 1024;
-constexpr int kSlotsPerLoader = kPatchSlots / 4;
+constexpr int kSlotsPerLoader = (kPatchSlots + 3) / 4;
 
 }  // namespace
 
@@ -112,12 +123,13 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     constexpr int WC = BNH / 32;                        // cout tiles per consumer
     constexpr int WBYTES = BN * 128;                    // one weight slot
     constexpr int WL = BN / 32;                         // weight LDS-DMA pieces per loader wave per step
-    constexpr int SROWS = ES == 2 ? 16 : 8;             // pixels per epilogue round (per wave)
+    constexpr int RING = BN == 128 ? kRing : 3;         // (the 64-cout kernels have LDS to spare but gain nothing)
+    constexpr int SROWS = (ES == 2 ? 16 : 8) / ((RING == 4 && BN == 128) ? 2 : 1);   // pixels per epilogue round (per wave)
     constexpr int SSTRIDE = BNH * ES + 16;              // staging row stride (bytes)
     constexpr int OFF_W = 2 * kPatchBytes;
-    constexpr int OFF_S = OFF_W + 3 * WBYTES;
-    constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the current / next item (two 1-KiB LDS-DMA pieces)
-    constexpr int LDS = OFF_B + 2048;
+    constexpr int OFF_S = OFF_W + RING * WBYTES;
+    constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the next item (one 1-KiB LDS-DMA piece)
+    constexpr int LDS = OFF_B + 1024;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
 
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 for (int k = 0; k < WL; ++k) glds(wfixed ? p.w + (woff[k] & 0xffffu) : wbase + wk + woff[k], dst + (lw + 4 * k) * 1024);
             }
             ++ws;
-            wslot = wslot == 2 ? 0 : wslot + 1;
+            wslot = wslot == RING - 1 ? 0 : wslot + 1;
             wk += (unsigned)(p.Cin * ES);
             if (++w_tap == 9) {
                 w_tap = 0;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
         };
         auto load_patch = [&](int j, unsigned ccoff, char *dstbuf) {
-            if (!live) return;
+            if (!live || lw + 4 * j >= kPatchSlots) return;
             const unsigned o = poff[j];
             glds(o == 0xFFFFFFFFu ? p.zero : (pfixed ? p.in + (o & 0xfffffu) : p.in + (size_t)o + ccoff), dstbuf + (lw + 4 * j) * 1024);
         };
@@ -240,8 +252,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             patch_table(item0);
 #pragma unroll
             for (int j = 0; j < kSlotsPerLoader; ++j) load_patch(j, 0u, smem);
-            load_weights();
-            if (n_steps > 1) load_weights();
+#pragma unroll
+            for (int k = 0; k < RING - 1; ++k)
+                if (k < n_steps) load_weights();
             next_patch_chunk();
             if (lw == 0 && live)
                 glds(lane < BN / 4 ? (const char *)(p.bias + (item0 % p.n_tiles) * BN) + lane * 16 : p.zero, smem + OFF_B);
@@ -249,7 +262,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        int tap = 0, c_it = 0, c_cc = 0;
+        int tap = 0, c_it = 0, c_cc = 0, carried = 0;
+        const int last_piece = lw + 4 * (kSlotsPerLoader - 1) < kPatchSlots ? 1 : 0;
         for (int g = 0; g < n_steps; ++g) {
             // operands of step g are in LDS.  Issue the weights of step g+2 and this tap's share of the
             // NEXT chunk's patch (taps 0-4: two pieces, tap 5: one); then make sure everything issued
@@ -270,17 +284,19 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                     case 2: load_patch(4, ccoff, dstbuf); load_patch(5, ccoff, dstbuf); issued += 2; break;
                     case 3: load_patch(6, ccoff, dstbuf); load_patch(7, ccoff, dstbuf); issued += 2; break;
                     case 4: load_patch(8, ccoff, dstbuf); load_patch(9, ccoff, dstbuf); issued += 2; break;
-                    default: load_patch(10, ccoff, dstbuf); issued += 1; break;
+                    default: load_patch(10, ccoff, dstbuf); issued += last_piece; break;
                 }
             }
             if (lw == 0 && c_cc == nchunks - 1 && tap == 6 && c_it + 1 < n_it) {
                 // the NEXT item's bias -> the other LDS bias slot (the consumers initialise their
                 // accumulators from it when that item starts; this item reads slot c_it & 1)
                 const int nt = (item0 + (c_it + 1) * istride) % p.n_tiles;
-                if (live) glds(lane < BN / 4 ? (const char *)(p.bias + nt * BN) + lane * 16 : p.zero, smem + OFF_B + ((c_it + 1) & 1) * 1024);
+                if (live) glds(lane < BN / 4 ? (const char *)(p.bias + nt * BN) + lane * 16 : p.zero, smem + OFF_B);
                 issued += 1;
             }
-            wait_vmcnt(live ? issued : 0);
+            // ring of 3: everything issued before this step has landed; ring of 4: before the previous step
+            wait_vmcnt(live ? issued + (RING == 4 ? carried : 0) : 0);
+            carried = issued;
             __builtin_amdgcn_s_barrier();
             if (++tap == 9) {
                 tap = 0;
@@ -492,7 +508,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     };
     // accumulators start at the bias (staged into LDS by loader wave 0 one item ahead)
     auto init_acc = [&](int it_) {
-        const char *bsrc = smem + OFF_B + (it_ & 1) * 1024;
+        const char *bsrc = smem + OFF_B;
+        (void)it_;
 #pragma unroll
         for (int ci = 0; ci < WC; ++ci)
 #pragma unroll
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         __builtin_amdgcn_s_barrier();
         // ---- advance to step g+1 and start its first reads, THEN finish this step's last K-slice ----
         const bool item_done = tap == 8 && cc == nchunks - 1;
-        wslot = wslot == 2 ? 0 : wslot + 1;
+        wslot = wslot == RING - 1 ? 0 : wslot + 1;
         ++tap;
         if (++tq == 3) {
             tq = 0;
