@@ -73,18 +73,32 @@ template <> __device__ __forceinline__ u32x4 pack16<float>(const float *in)
     for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(in[i]);
     return r;
 }
+// two floats -> one dword of 16-bit elements with ONE packed convert (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32; the
+// element-wise form costs two converts, a shift and an or per pair)
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float fl2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(fl2{a, b}, bf2));
+}
+__device__ __forceinline__ unsigned pack2_f16(float a, float b)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float fl2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(fl2{a, b}, h2));
+}
 template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float *in)
 {
     u32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (unsigned)f32_to_bf16(in[2 * i]) | ((unsigned)f32_to_bf16(in[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) r[i] = pack2_bf16(in[2 * i], in[2 * i + 1]);
     return r;
 }
 template <> __device__ __forceinline__ u32x4 pack16<f16_t>(const float *in)
 {
     u32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (unsigned)f32_to_f16(in[2 * i]) | ((unsigned)f32_to_f16(in[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) r[i] = pack2_f16(in[2 * i], in[2 * i + 1]);
     return r;
 }
 

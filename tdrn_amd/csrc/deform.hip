@@ -108,17 +108,44 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
     int coff[PA][4];      // element offsets of the four corners (relative to `in`)
     float cw[PA][4];      // bilinear weights (0 when the tap is rejected)
 
+    // offsets of the NEXT (tap, group) are fetched one tap ahead: a tap lasts cpg/CK K-steps, so they have landed
+    // long before tap_params() needs them and the K loop never waits on an offset load
+    float noff[PA][2];
+    auto fetch_offsets = [&](int br_, int ti_, int tj_, int g_) {
+        const DeformBranchP &B = p.br[br_];
+        const int tapidx = ti_ * B.kw + tj_;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            noff[i][0] = 0.f;
+            noff[i][1] = 0.f;
+            if (mrow[i] >= 0) {
+                const float *op = B.off + mrow[i] * B.off_stride + (size_t)g_ * 2 * B.kh * B.kw + 2 * tapidx;
+                noff[i][0] = op[0];
+                noff[i][1] = op[1];
+            }
+        }
+    };
     auto tap_params = [&]() {
         const DeformBranchP &B = p.br[br];
-        const int tapidx = ti * B.kw + tj;
         const int cpg = p.Cin / B.G;
+        float offh[PA], offw[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) { offh[i] = noff[i][0]; offw[i] = noff[i][1]; }
+        {   // the tap after this one (same stepping as advance())
+            int nb = br, ni = ti, nj = tj, ng = g + 1;
+            if (ng == B.G) {
+                ng = 0;
+                if (++nj == B.kw) { nj = 0; ++ni; }
+                if (ni == B.kh) { ni = 0; ++nb; }
+            }
+            if (nb < p.n_branches) fetch_offsets(nb, ni, nj, ng);
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
             int o1 = ibase[i], o2 = ibase[i], o3 = ibase[i], o4 = ibase[i];
             if (mrow[i] >= 0) {
-                const float *op = B.off + mrow[i] * B.off_stride + (size_t)g * 2 * B.kh * B.kw + 2 * tapidx;
-                const float offset_h = op[0], offset_w = op[1];
+                const float offset_h = offh[i], offset_w = offw[i];
                 const int h_in = ho_[i] * B.stride - B.pad, w_in = wo_[i] * B.stride - B.pad;
                 const float h_im = (float)(h_in + ti * B.dil) + offset_h;
                 const float w_im = (float)(w_in + tj * B.dil) + offset_w;
@@ -166,7 +193,8 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
 #pragma unroll
         for (int i = 0; i < PA; ++i)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) raw[i][k] = *(const u32x4 *)(p.in + (size_t)coff[i][k] * ES + coffs);
+            for (int k = 0; k < 4; ++k)      // 32-bit byte offset from the scalar base (fill_params bounds the tensor below 4 GiB)
+                raw[i][k] = *(const u32x4 *)(p.in + (unsigned)((unsigned)coff[i][k] * (unsigned)ES + (unsigned)coffs));
     };
     float fw[PA][4];      // weights that belong to the registers in flight
     auto latch_weights = [&]() {
@@ -225,6 +253,7 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
         }
     };
 
+    fetch_offsets(0, 0, 0, 0);
     tap_params();
     issue(0);
     latch_weights();
@@ -290,7 +319,7 @@ static int fill_params(const DeformArgs &a, DeformParams &p)
     const int es = dtype_bytes(a.dtype), ck = 128 / es;
     if (a.Npad % 32 || a.Npad > 128 || a.Cout > a.Npad || a.Cout < 1) return TDRN_E_UNSUPPORTED;
     if (a.split < a.Cout && !a.out1) return TDRN_E_ARG;
-    if ((long long)a.B * a.H * a.W * a.Cin >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
+    if ((long long)a.B * a.H * a.W * a.Cin * es >= (1ll << 32)) return TDRN_E_UNSUPPORTED;     // 32-bit byte offsets in the gather
     p.in = (const char *)a.in;
     p.zero = (const char *)a.zero_page;
     p.n_branches = a.n_branches;
