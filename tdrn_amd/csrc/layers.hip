@@ -114,16 +114,10 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const float *__res
             wr[ci][s2] = (k < 27 && co < Cout) ? w[co * 27 + k] : 0.f;
         }
     }
-    float bq[2][4][4];                                   // bias of my accumulator rows: cout = 32*ci + 8*g + 4*hh + j
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = ci * 32 + 8 * g + 4 * hh + j;
-                bq[ci][g][j] = co < Cout ? bias[co] : 0.f;
-            }
+    // bias of the 64 couts in LDS (32 registers otherwise: they cost the fourth wave per SIMD)
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    if (t < 64) bias_s[t] = t < Cout ? bias[t] : 0.f;
+    __syncthreads();
     char *stg = stage + wave * 32 * TS;
     constexpr int CPR = 64 * ES / 16;                    // 16-B chunks per pixel
     constexpr int RPI = 64 / CPR;                        // pixels per wave store instruction
@@ -173,9 +167,11 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const float *__res
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g) {            // accumulator rows: cout = 32*ci + 8*g + 4*hh + j
+                    const f32x4 bv = *(const f32x4 *)(bias_s + ci * 32 + 8 * g + 4 * hh);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ci][4 * g + j] = bq[ci][g][j];
+                    for (int j = 0; j < 4; ++j) acc[ci][4 * g + j] = bv[j];
+                }
             const int porg = (orow * STRIDE) * IW + r32 * STRIDE;      // halo origin of my pixel
             float xv[14];
 #pragma unroll
