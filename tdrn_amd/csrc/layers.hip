@@ -390,12 +390,106 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(const char *__restrict__ i
     }
 }
 
+// Row-strip version: a thread produces TW = 4 consecutive outputs of one row for one 16-B channel chunk.  The
+// three input rows are walked once, every loaded column feeds up to three outputs (18 loads per 4 outputs at
+// stride 1 instead of 36; 27 instead of 36 at stride 2), and when the channel chunk of a thread is the same in
+// every grid-stride iteration (256 % (C/P16) == 0) its 9 x P16 fp32 weights stay in registers for the launch
+// instead of being re-read per output.  Same arithmetic order per output as dwconv3_kernel (taps row-major).
+template <typename DT, int STRIDE>
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(const char *__restrict__ in, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, char *__restrict__ out, int B,
+                                                            int H, int W, int Ho, int Wo, int C, int relu)
+{
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int ES = elem_traits<DT>::bytes;
+    constexpr int TW = 4;
+    constexpr int NCOL = (TW - 1) * STRIDE + 3;            // input columns under one strip
+    const int cpr = C / P16;
+    const int wg = (Wo + TW - 1) / TW;                     // strips per output row
+    const long long total = (long long)B * Ho * wg * cpr;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    const bool fixed_ch = (256 % cpr) == 0;                // then i % cpr never changes for this thread
+    float wt[9][P16], bs[P16];
+    int ch_loaded = -1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int ch = fixed_ch ? (int)(threadIdx.x % cpr) : (int)(i % cpr);
+        long long r = i / cpr;
+        const int sg = (int)(r % wg);
+        r /= wg;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        if (ch != ch_loaded) {
+            ch_loaded = ch;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < P16; ++j) wt[t][j] = w[(size_t)t * C + ch * P16 + j];
+#pragma unroll
+            for (int j = 0; j < P16; ++j) bs[j] = bias[ch * P16 + j];
+        }
+        const int wo0 = sg * TW;
+        float acc[TW][P16];
+#pragma unroll
+        for (int o = 0; o < TW; ++o)
+#pragma unroll
+            for (int j = 0; j < P16; ++j) acc[o][j] = bs[j];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int hi = ho * STRIDE - 1 + rr;
+            if ((unsigned)hi >= (unsigned)H) continue;     // zero padding row: contributes nothing
+            const char *rowp = in + (((size_t)b * H + hi) * W) * C * ES + (size_t)ch * 16;
+            u32x4 raw[NCOL];
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                const int wi = wo0 * STRIDE - 1 + c;
+                raw[c] = (unsigned)wi < (unsigned)W ? *(const u32x4 *)(rowp + (size_t)wi * C * ES) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                float v[P16];
+                unpack16<DT>(raw[c], v);
+#pragma unroll
+                for (int o = 0; o < TW; ++o) {
+                    const int q = c - o * STRIDE;          // tap column of output o that reads input column c
+                    if (q >= 0 && q < 3) {
+#pragma unroll
+                        for (int j = 0; j < P16; ++j) acc[o][j] = fmaf(wt[rr * 3 + q][j], v[j], acc[o][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            if (wo0 + o >= Wo) break;
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < P16; ++j) acc[o][j] = fmaxf(acc[o][j], 0.f);
+            }
+            *(u32x4 *)(out + ((((size_t)b * Ho + ho) * Wo + wo0 + o) * C + (size_t)ch * P16) * ES) = pack16<DT>(acc[o]);
+        }
+    }
+}
+
 int launch_dwconv3(const void *in, const float *w, const float *bias, void *out, int B, int H, int W, int C,
                    int stride, int relu, int dtype, hipStream_t s)
 {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int per16 = 16 / dtype_bytes(dtype);
     if (C % per16) return TDRN_E_UNSUPPORTED;
+    static int strip = -1;
+    if (strip < 0) { const char *e = getenv("TDRN_DW_STRIP"); strip = e ? atoi(e) : 1; }
+    if (strip && (stride == 1 || stride == 2) && Wo >= 4) {
+        const long long total = (long long)B * Ho * ((Wo + 3) / 4) * (C / per16);
+        dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+#define LS(DT)                                                                                                                         \
+    do {                                                                                                                               \
+        if (stride == 1) hipLaunchKernelGGL((dwconv3_strip_kernel<DT, 1>), grid, dim3(256), 0, s, (const char *)in, w, bias, (char *)out, B, H, W, Ho, Wo, C, relu); \
+        else hipLaunchKernelGGL((dwconv3_strip_kernel<DT, 2>), grid, dim3(256), 0, s, (const char *)in, w, bias, (char *)out, B, H, W, Ho, Wo, C, relu);             \
+    } while (0)
+        if (dtype == TDRN_F32) LS(float); else if (dtype == TDRN_BF16) LS(bf16_t); else LS(f16_t);
+#undef LS
+        return hip_status(hipGetLastError());
+    }
     const long long total = (long long)B * Ho * Wo * (C / per16);
     dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
 #define L(DT) hipLaunchKernelGGL((dwconv3_kernel<DT>), grid, dim3(256), 0, s, (const char *)in, w, bias, (char *)out, B, H, W, Ho, Wo, C, stride, relu)
