@@ -93,7 +93,7 @@ struct tdrn_net {
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_zero = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
     std::vector<int> tensor_lane;
     std::vector<char> tensor_shared;
@@ -574,6 +574,26 @@ struct tdrn_net {
         }
         if (rc != TDRN_OK) return rc;
         if (plan_error != TDRN_OK) return plan_error;
+        // L2Norm of conv4_3 / conv5_3 right behind its producer and on a side lane: it is HBM-bound and needs no
+        // LDS, so it runs under the next (LDS-filling) conv of the trunk, and the lateral TCB convs and ARM heads
+        // that read it can start while conv5 / fc6 / fc7 -- which leave CUs idle -- are still running, instead of
+        // queueing behind fc7 on the main lane.
+        {
+            const char *le = getenv("TDRN_L2_EARLY");
+            int side = 1;
+            for (size_t i = 0; i < ops.size() && !(le && atoi(le) == 0); ++i) {
+                if (ops[i].kind != OP_L2NORM) continue;
+                size_t prod = i;
+                for (size_t j = 0; j < i; ++j)
+                    if (ops[j].out == ops[i].in || ops[j].pool_t == ops[i].in) prod = j;
+                if (prod == i) continue;
+                Op o = ops[i];
+                o.lane = side;
+                side = side == 1 ? 2 : 1;
+                ops.erase(ops.begin() + (long)i);
+                ops.insert(ops.begin() + (long)prod + 1, o);
+            }
+        }
         // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
         {
@@ -626,6 +646,7 @@ struct tdrn_net {
             TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         }
         TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_zero, hipEventDisableTiming));
         tensor_ev.assign(tensors.size(), nullptr);
         for (size_t t = 0; t < tensors.size(); ++t)
             if (tensor_shared[t]) TDRN_HIP_TRY(hipEventCreateWithFlags(&tensor_ev[t], hipEventDisableTiming));
@@ -837,6 +858,27 @@ struct tdrn_net {
             TDRN_TRY(init_lanes());
             TDRN_HIP_TRY(hipEventRecord(ev_fork, s0));
         }
+        // split two-branch deformable heads accumulate into zeroed outputs: zero them on a side stream at the very
+        // start (under the first conv) instead of in front of the deform launch on the critical path
+        bool zeroed_early = false;
+        if (lanes && deform_split) {
+            const Op *dsplit = nullptr;
+            int n_deform_groups = 0;
+            for (size_t k = 0; k < ops.size(); ++k)
+                if (ops[k].kind == OP_DEFORM) {
+                    if (ops[k].n_branches == 2 && !dsplit) dsplit = &ops[k];
+                    if (k == 0 || ops[k - 1].kind != OP_DEFORM) ++n_deform_groups;
+                }
+            if (dsplit && n_deform_groups == 1) {        // (one merged launch writes these outputs; nothing else does)
+                float *locbase0 = dsplit->out_kind == OUT_ARM_LOC ? io->arm_loc : io->odm_loc;
+                TDRN_HIP_TRY(hipStreamWaitEvent(side[0], ev_fork, 0));
+                lane_used[1] = true;
+                TDRN_HIP_TRY(hipMemsetAsync(locbase0, 0, (size_t)B * P * 4 * sizeof(float), side[0]));
+                TDRN_HIP_TRY(hipMemsetAsync(io->conf, 0, (size_t)B * P * C * sizeof(float), side[0]));
+                TDRN_HIP_TRY(hipEventRecord(ev_zero, side[0]));
+                zeroed_early = true;
+            }
+        }
         DeformArgs dargs[4];
         int n_dargs = 0;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
@@ -955,9 +997,13 @@ struct tdrn_net {
                     if (!deform_batched) {      // all pyramid levels in one launch
                         const bool split = o.n_branches == 2 && deform_split;
                         if (split) {             // the two branches accumulate into zeroed outputs
-                            float *locbase0 = o.out_kind == OUT_ARM_LOC ? io->arm_loc : io->odm_loc;
-                            TDRN_HIP_TRY(hipMemsetAsync(locbase0, 0, (size_t)B * P * 4 * sizeof(float), s));
-                            TDRN_HIP_TRY(hipMemsetAsync(io->conf, 0, (size_t)B * P * C * sizeof(float), s));
+                            if (zeroed_early) {
+                                TDRN_HIP_TRY(hipStreamWaitEvent(s, ev_zero, 0));
+                            } else {
+                                float *locbase0 = o.out_kind == OUT_ARM_LOC ? io->arm_loc : io->odm_loc;
+                                TDRN_HIP_TRY(hipMemsetAsync(locbase0, 0, (size_t)B * P * 4 * sizeof(float), s));
+                                TDRN_HIP_TRY(hipMemsetAsync(io->conf, 0, (size_t)B * P * C * sizeof(float), s));
+                            }
                         }
                         rc = launch_deform_multi(dargs, n_dargs, s, split ? 1 : 0);
                         n_dargs = 0;
@@ -1050,6 +1096,7 @@ void tdrn_net_destroy(tdrn_net *net)
         if (net->side[i]) (void)hipStreamDestroy(net->side[i]);
     }
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_zero) (void)hipEventDestroy(net->ev_zero);
     delete net;
 }
 
