@@ -92,6 +92,7 @@ struct tdrn_net {
     int cur_lane = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
+    int splitk_ref_batch = 8;           // split-K factors are planned for this batch and used for every batch (TDRN_SPLITK_REF)
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_zero = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
@@ -594,6 +595,7 @@ struct tdrn_net {
                 ops.insert(ops.begin() + (long)prod + 1, o);
             }
         }
+        if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 8;
         // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
         {
@@ -603,7 +605,7 @@ struct tdrn_net {
                 if (o.kind != OP_CONV || o.pool_t >= 0) continue;
                 const Tensor &ti = tensors[o.in];
                 ConvArgs a;
-                a.B = 8; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
+                a.B = splitk_ref_batch; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
                 a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                 a.phases = o.phases; a.dtype = cfg.dtype; a.out_f32 = o.out_kind != OUT_TENSOR;
                 o.splitk = conv_splitk_choice(a);
@@ -616,6 +618,13 @@ struct tdrn_net {
                     const size_t per_sample = align_up((size_t)o.splitk * o.phases * a.Ho * a.Wo * o.Npad * sizeof(float), 256);
                     if (per_sample > lane_bytes[o.lane]) lane_bytes[o.lane] = per_sample;
                 }
+            }
+            if (const char *pd = getenv("TDRN_PLAN_DUMP")) {
+                if (atoi(pd))
+                    for (const Op &o : ops)
+                        if (o.kind == OP_CONV)
+                            fprintf(stderr, "plan: %-28s lane %d  %dx%d k%d s%d d%d  Cin %4d Cout %4d  splitk %d  %s\n", o.w.c_str(), o.lane,
+                                    o.hw >> 16, o.hw & 0xffff, o.k, o.stride, o.dil, o.Cin, o.Cout, o.splitk, o.stat == ST_CONV3 ? "patch" : "igemm");
             }
             for (int l = 0; l < kLanes; ++l) {
                 splitk_off[l] = ws_per_sample;
