@@ -87,6 +87,9 @@ __device__ __forceinline__ unsigned pack2_f16(float a, float b)
     typedef float fl2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(unsigned, __builtin_convertvector(fl2{a, b}, h2));
 }
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) { return pack2_bf16(a, b); }
+template <> __device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) { return pack2_f16(a, b); }
 template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float *in)
 {
     u32x4 r;

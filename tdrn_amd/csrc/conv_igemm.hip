@@ -415,8 +415,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
             if constexpr (ES == 4) {
                 *(f32x4 *)(p.out + eo * 4) = v;
             } else {
-                const unsigned lo = (unsigned)from_f32<DT>(v[0]).v | ((unsigned)from_f32<DT>(v[1]).v << 16);
-                const unsigned hi = (unsigned)from_f32<DT>(v[2]).v | ((unsigned)from_f32<DT>(v[3]).v << 16);
+                const unsigned lo = pack2<DT>(v[0], v[1]), hi = pack2<DT>(v[2], v[3]);
                 *(uint2 *)(p.out + eo * 2) = make_uint2(lo, hi);
             }
             continue;

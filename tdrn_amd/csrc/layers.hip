@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const float *__res
                     if constexpr (ES == 4) {
                         *(f32x4 *)d = f32x4{q4[0], q4[1], q4[2], q4[3]};
                     } else {
-                        *(uint2 *)d = make_uint2((unsigned)from_f32<DT>(q4[0]).v | ((unsigned)from_f32<DT>(q4[1]).v << 16),
-                                                 (unsigned)from_f32<DT>(q4[2]).v | ((unsigned)from_f32<DT>(q4[3]).v << 16));
+                        *(uint2 *)d = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
                     }
                 }
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): my LDS writes are done
