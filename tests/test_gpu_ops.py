@@ -235,6 +235,22 @@ def test_detect_selection_fallbacks_match_oracle():
     np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
 
 
+def test_detect_coco_class_count_matches_oracle():
+    """81 classes (COCO, data/config.py COCO_300): the score transpose tile and the per-(image, class) grid at
+    a class count other than 21; D8-like regime plus one dense class."""
+    B, P, C = 2, 6375, 81
+    loc, arm, conf = synth.synth_detect_inputs(B, P, C, 9.5, seed=21)
+    conf = conf.copy()
+    conf[:P, 7] = (0.02 + 0.5 * np.random.Generator(np.random.PCG64(4)).random(P)).astype(np.float32)   # every prior a candidate
+    pri = PriorBox(mb_cfg["VOC_320"]).forward()
+    det = Detect(C, 0, 200, 0.01, 0.45)
+    out = det.forward(_cu(loc), _cu(conf), pri.to(DEV), arm_loc_data=_cu(arm)).cpu().numpy()
+    ref = orc.detect(loc, conf, pri.numpy(), arm, (320,) * 4, num_classes=C)
+    assert out.shape == (B, C, 200, 5)
+    assert np.array_equal(out[..., 0], ref[..., 0])
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+
+
 def test_detect_empty_and_errors():
     P = 6375
     pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
