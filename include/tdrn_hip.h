@@ -13,7 +13,8 @@
  *     (so they can be captured into a hipGraph); the two exceptions are marked COMPAT.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
  *     enqueued on it and the call returns without synchronising unless stated.
- *   - thread-safe per (handle, stream); no global mutable state.
+ *   - thread-safe per (handle, stream).  The only process-wide state is idempotent memoisation: environment
+ *     switches (TDRN_*) read once, and "dynamic LDS limit raised" per (kernel, device).
  *
  * Each entry point cites the reference interface it replaces (paths relative to the upstream
  * SeanChenxy/TDRN tree).
@@ -81,6 +82,7 @@ TDRN_API int tdrn_deform_conv_forward(const float *input, const float *weight,
  *     cpu_nms(ndarray[float32, ndim=2] dets, float thresh) -> list   utils/nms/cpu_nms.pyx:17-68
  *     (dispatcher utils/nms_wrapper.py:23-31, called at layers/functions/detection.py:60)
  *   dets (n,5) device fp32 rows [x1,y1,x2,y2,score] in pixel units ("+1" convention), ANY order;
+ *   any n (above 16384 boxes the sort keys live in the workspace instead of LDS);
  *   sorted on device by (score desc, index asc).  Suppression when IoU >= thresh
  *   (strict_gt = 0, cpu_nms.pyx:66) or IoU > thresh (strict_gt = 1, nms_kernel.cu:71); the IoU
  *   is fp32 and compared against the double `thresh` exactly as the Cython code does.
@@ -119,12 +121,20 @@ TDRN_API int tdrn_prior_box(int n_maps, const int *feature_maps, double image_si
  *   scale: 4 HOST floats (the caller's [w,h,w,h]; evaluate.py:461)
  *   out (B,C,top_k,5) device fp32, fully overwritten (class 0 and unused slots = 0)
  *   counts_out (B*C) device int32 or NULL: survivors per (image,class), capped at top_k. */
+/* Any P (no LDS-derived limit: the 1216-pixel scale of multi_eval.py:24 has P = 92055).
+ * tdrn_detect_dev_scale: the same with `scale` as 4 DEVICE floats (16-byte aligned) -- evaluate.py:461 builds
+ * the scale as a CUDA tensor; reading it on the device keeps the call free of host synchronisation. */
 TDRN_API size_t tdrn_detect_workspace_bytes(int B, int P, int C, int top_k);
 TDRN_API int tdrn_detect(const float *loc, const float *conf, const float *priors,
                          const float *arm_loc, const float *scale_host, int B, int P, int C,
                          int top_k, float conf_thresh, double nms_thresh, float *out,
                          int32_t *counts_out, void *workspace, size_t workspace_bytes,
                          void *stream);
+TDRN_API int tdrn_detect_dev_scale(const float *loc, const float *conf, const float *priors,
+                                   const float *arm_loc, const float *scale_dev, int B, int P, int C,
+                                   int top_k, float conf_thresh, double nms_thresh, float *out,
+                                   int32_t *counts_out, void *workspace, size_t workspace_bytes,
+                                   void *stream);
 
 /* Preprocess -- replaces base_transform + the channel swap of
  *     data/__init__.py:7-12 (cv2.resize(image,(S,S)) -> float32 -> -= mean) and data/voc0712.py:467-468

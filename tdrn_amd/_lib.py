@@ -58,6 +58,8 @@ _SIGS = {
     "tdrn_detect_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "tdrn_detect": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_double, C.c_void_p,
                                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tdrn_detect_dev_scale": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_double, C.c_void_p,
+                                                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tdrn_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(C.c_void_p)]),
     "tdrn_net_destroy": (None, [C.c_void_p]),
     "tdrn_net_param_count": (C.c_int, [C.c_void_p]),

@@ -124,7 +124,12 @@ int tdrn_gpu_nms_host(int *keep_out, int *num_out, const float *boxes_host, int 
     if (boxes_dim != 5) return TDRN_E_SHAPE;
     *num_out = 0;
     if (boxes_num == 0) return TDRN_OK;
-    if (device_id >= 0) TDRN_HIP_TRY(hipSetDevice(device_id));
+    // the reference's _nms switches the device and never switches back (nms_kernel.cu:21-32); a frame-sharded rank
+    // must keep ITS device current, so the previous one is restored on every exit
+    int prev_dev = -1;
+    TDRN_HIP_TRY(hipGetDevice(&prev_dev));
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{device_id >= 0 && device_id != prev_dev ? prev_dev : -1};
+    if (device_id >= 0 && device_id != prev_dev) TDRN_HIP_TRY(hipSetDevice(device_id));
     const size_t bytes = (size_t)boxes_num * 5 * sizeof(float), wsb = nms_workspace_bytes(boxes_num);
     char *dev = nullptr;
     TDRN_HIP_TRY(hipMalloc((void **)&dev, align_up(bytes, 256) + wsb + align_up((size_t)boxes_num * 4, 256) + 256));
@@ -211,7 +216,15 @@ int tdrn_detect(const float *loc, const float *conf, const float *priors, const 
                 int B, int P, int C, int top_k, float conf_thresh, double nms_thresh, float *out, int32_t *counts_out,
                 void *workspace, size_t workspace_bytes, void *stream)
 {
-    return launch_detect(loc, conf, priors, arm_loc, scale_host, B, P, C, top_k, conf_thresh, nms_thresh, out, counts_out,
+    return launch_detect(loc, conf, priors, arm_loc, scale_host, 0, B, P, C, top_k, conf_thresh, nms_thresh, out, counts_out,
+                         workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int tdrn_detect_dev_scale(const float *loc, const float *conf, const float *priors, const float *arm_loc, const float *scale_dev,
+                          int B, int P, int C, int top_k, float conf_thresh, double nms_thresh, float *out, int32_t *counts_out,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    return launch_detect(loc, conf, priors, arm_loc, scale_dev, 1, B, P, C, top_k, conf_thresh, nms_thresh, out, counts_out,
                          workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -11,13 +11,15 @@
 // candidates are ordered by (score desc, prior index asc).  Given identical fp32 boxes/scores the keep
 // lists equal cpu_nms's on tie-free scores.
 //
-// Pipeline (3 launches, no memset, no host sync):
+// Pipeline (2 launches, no memset, no host sync, any number of priors):
 //   detect_decode_kernel     : two-stage decode, normalised boxes + boxes*scale; scores -> class-major rows
-//   detect_select_nms_kernel : per (image,class): class row -> LDS; then, up to 1024 candidates at a time in
-//                              descending score (radix-select of a score threshold, compaction, bitonic
-//                              sort), greedy NMS against an LDS-resident keep list until top_k boxes are
-//                              kept or the candidates run out; pack + zero-fill the output rows
-//   detect_nms_kernel        : redo, with one full sort, of segments where >1024 candidates tie on score
+//   detect_select_nms_kernel : per (image,class): class row -> score keys (in LDS while 4*P bytes fit beside the
+//                              rest, else in place over the class row in global memory); then, up to 1024
+//                              candidates at a time in descending score (radix-select of a score threshold,
+//                              compaction, bitonic sort), greedy NMS against an LDS-resident keep list until
+//                              top_k boxes are kept or the candidates run out; pack + zero-fill the output rows.
+//                              More than 1024 candidates with ONE score are taken 1024 at a time in ascending
+//                              prior index (that is their place in the order), so LDS use never depends on P.
 #include <cmath>
 #include <cstring>
 
@@ -83,9 +85,11 @@ int launch_center_size(const float *boxes, int P, float *out, hipStream_t s)
 // workgroups of the NMS launch read 4*P contiguous bytes instead of a C-strided column.
 __global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restrict__ loc, const float *__restrict__ arm,
                                                             const float *__restrict__ priors, const float *__restrict__ conf,
-                                                            int B, int P, int C, f32x4 scale, float *__restrict__ boxes,
+                                                            int B, int P, int C, f32x4 scale, const float *__restrict__ scale_dev,
+                                                            float *__restrict__ boxes,
                                                             float *__restrict__ sboxes, float *__restrict__ scoresT)
 {
+    if (scale_dev) scale = *(const f32x4 *)scale_dev;       // the caller's [w,h,w,h] lives on the device (evaluate.py:461)
     extern __shared__ __attribute__((aligned(16))) float tile[];       // 256 rows x (C|1) floats
     const long long i0 = (long long)blockIdx.x * 256, total = (long long)B * P;
     const long long i = i0 + threadIdx.x;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float *__restr
 // 128-key span, so those stages need no workgroup barrier (LDS operations of one wave complete in order);
 // only the j >= 128 stages and the hand-over between the two kinds synchronise the workgroup.  The loads
 // of a stage are issued together (four pairs at a time) so that one LDS round trip covers them.
-__device__ __forceinline__ void bitonic_stage(unsigned long long *k, int N, int kk, int j, int tid, int nthreads)
+__device__ __forceinline__ void bitonic_stage(unsigned long long *k, int N, int kk, int j, int tid, int nthreads, int base = 0)
 {
     for (int i0 = tid; i0 < (N >> 1); i0 += 4 * nthreads) {
         unsigned long long x[4], y[4];
@@ -134,7 +138,7 @@ __device__ __forceinline__ void bitonic_stage(unsigned long long *k, int N, int 
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + r * nthreads;
             if (i < (N >> 1)) {
-                const bool desc = (a[r] & kk) == 0;
+                const bool desc = ((base + a[r]) & kk) == 0;      // base: where k[0] sits in a larger (global) sort
                 if ((x[r] < y[r]) == desc) { k[a[r]] = y[r]; k[a[r] + j] = x[r]; }
             }
         }
@@ -380,7 +384,7 @@ __device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int t
         });
 }
 
-// LDS layout shared by both kernels: sk[kcap] | kept (20 B x top_k) | ctl[16] | alive[256 B] | wsum[8] | (select: hist[256] | sc[P])
+// LDS layout: sk[kcap] | kept (20 B x top_k) | ctl[16] | alive[256 B] | wsum[8] | hist[256] | (LDS keys: sc[P])
 __device__ __forceinline__ void detect_lds(unsigned long long *dsm, int kcap, int top_k, unsigned long long *&sk, void *&kept,
                                            int *&ctl, unsigned char *&alive_s, int *&wsum, unsigned *&extra)
 {
@@ -391,20 +395,23 @@ __device__ __forceinline__ void detect_lds(unsigned long long *dsm, int kcap, in
     wsum = (int *)(alive_s + 256);
     extra = (unsigned *)(wsum + 8);
 }
-static size_t detect_lds_bytes(int kcap, int top_k) { return (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 64 + 256 + 32; }
+static size_t detect_lds_bytes(int kcap, int top_k) { return (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 64 + 256 + 32 + 256 * 4; }
 
-// Main launch.  The workgroup loads its class row (score > conf_thresh, detection.py:53) into LDS.  Greedy
-// NMS walks candidates in descending score (cpu_nms.pyx:31) and Detect stops at top_k survivors
-// (detection.py:63), so the row is consumed in CHUNKS of at most kcap (1024) candidates: a radix select (8
-// bits a level, most significant first, stopping as soon as a level leaves kcap/2..kcap candidates above a
-// bin boundary) finds a score threshold, the candidates above it and not yet consumed are compacted,
-// sorted, and handed to the resumable NMS.  Every chunk is a contiguous piece of the descending order, so
-// the decisions are the sequential algorithm's.  If more than kcap candidates share one score no threshold
-// separates them: the segment raises overflow[seg] and the second launch redoes it with one full sort.
+// The workgroup turns its class row (score > conf_thresh, detection.py:53) into score keys.  Greedy NMS walks
+// candidates in descending score (cpu_nms.pyx:31) and Detect stops at top_k survivors (detection.py:63), so the
+// row is consumed in CHUNKS of at most kcap (1024) candidates: a radix select (8 bits a level, most significant
+// first, stopping as soon as a level leaves kcap/2..kcap candidates above a bin boundary) finds a score
+// threshold, the candidates above it and not yet consumed are compacted, sorted, and handed to the resumable
+// NMS.  Every chunk is a contiguous piece of the descending order, so the decisions are the sequential
+// algorithm's.  If kcap or more candidates share ONE score no threshold separates them; their order is
+// ascending prior index, so that tie group is taken kcap at a time in index order ("tie mode").
+// GK = false: keys live in LDS (4*P bytes).  GK = true (P too large for that, e.g. the 1216-pixel scale of
+// multi_eval.py:24 with P = 92055): keys replace the scores of the class row in global memory, in place.
+template <bool GK>
 __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
-                                                                const float *__restrict__ scoresT, int P, int C, int top_k,
+                                                                float *scoresT, int P, int C, int top_k,
                                                                 float conf_thresh, NmsRule rule, int kcap,
-                                                                int *__restrict__ overflow, float *__restrict__ out,
+                                                                float *__restrict__ out,
                                                                 int *__restrict__ counts_out, long long *__restrict__ dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
@@ -414,20 +421,19 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
     unsigned long long *sk; void *kept_mem; int *ctl; unsigned char *alive_s; int *wsum; unsigned *hist;
     detect_lds(dsm, kcap, top_k, sk, kept_mem, ctl, alive_s, wsum, hist);
     const KeepList kept(kept_mem, top_k);
-    unsigned *sc = hist + 256;
     const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // seg = b*C + cl
     const int cl = seg % C, b = seg / C;
+    float *row = scoresT + (size_t)seg * P;
+    unsigned *sc = GK ? (unsigned *)row : hist + 256;
     float *orow = out + (size_t)seg * top_k * 5;
-    if (tid == 0) overflow[seg] = 0;
     if (cl == 0) {                                                         // background: detection.py:51 skips it
         for (int i = tid; i < top_k * 5; i += 256) orow[i] = 0.f;
         if (counts_out && tid == 0) counts_out[seg] = 0;
         return;
     }
-    if (tid < 16) ctl[tid] = tid == 3 ? (int)0xFFFFFFFF : 0;              // [0] n, [1] nk, [2] OR, [3] AND, [4] bin, [5] remaining
+    if (tid < 16) ctl[tid] = tid == 3 ? (int)0xFFFFFFFF : 0;              // [0] n, [1] nk, [2] OR, [3] AND, [4] bin, [5] remaining, [6] next tie_lo
     __syncthreads();
-    // ---- scan: class row -> score keys in LDS (0 = below conf_thresh); loads issued five at a time --------
-    const float *row = scoresT + (size_t)seg * P;
+    // ---- scan: class row -> score keys (0 = below conf_thresh); loads issued five at a time --------
     int mycnt = 0;
     unsigned vor = 0u, vand = 0xFFFFFFFFu;
     for (int p0 = tid; p0 < P; p0 += 5 * 256) {
@@ -462,15 +468,22 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
     const unsigned diff = (unsigned)ctl[2] ^ (unsigned)ctl[3];
     const int shift0 = diff ? ((31 - __clz(diff)) & ~7) : 0;
     const unsigned mask0 = shift0 < 24 ? 0xFFFFFFFFu << (shift0 + 8) : 0u, prefix0 = (unsigned)ctl[3] & mask0;
-    const int L = ((P + 255) / 256) | 1;                 // compaction: L consecutive scores per thread (odd: conflict-free)
+    // compaction ranges.  LDS keys: L consecutive scores per thread (L odd: conflict-free).  Global keys: a
+    // contiguous quarter of the row per wave, read 64 keys (256 B) at a time.
+    const int L = ((P + 255) / 256) | 1;
     const int p_lo = tid * L < P ? tid * L : P, p_hi = p_lo + L < P ? p_lo + L : P;
+    const int Q = (((P + 3) / 4) + 63) & ~63;
+    const int q_lo = wave * Q < P ? wave * Q : P, q_hi = q_lo + Q < P ? q_lo + Q : P;
     const float *sb = sboxes + (size_t)b * P * 4, *nb = boxes + (size_t)b * P * 4;
     unsigned hi = 0xFFFFFFFFu;                           // candidates not yet consumed: 0 < key <= hi
+    bool tie = false;                                    // tie mode: the candidates with key == tie_key and prior >= tie_lo
+    unsigned tie_key = 0u;
+    int tie_lo = 0;
     int taken = 0, nk = 0;
     for (;;) {
         // ---- threshold: this chunk = unconsumed candidates with (key & mask) > prefix (mask = 0: all of them) ----
         unsigned prefix = 0u, mask = 0u;
-        if (n - taken > kcap) {
+        if (!tie && n - taken > kcap) {
             prefix = prefix0;
             mask = mask0;
             int remaining = kcap;
@@ -492,32 +505,62 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
                 __syncthreads();
                 if (kcap - remaining >= kcap / 2) break;
             }
+            if (remaining == kcap) {                     // nothing lies strictly above a score that >= kcap candidates share
+                tie = true;
+                tie_key = prefix;
+                tie_lo = 0;
+            }
         }
         DT_STAMP(stamps, 2);
-        // ---- compaction (order is irrelevant, the sort follows): per-thread counts, workgroup scan, scatter ----
+        auto selected = [&](unsigned v, int p) -> bool {
+            if (tie) return v == tie_key && p >= tie_lo;
+            return v && v <= hi && (mask ? (v & mask) > prefix : true);
+        };
+        // ---- compaction in ascending prior order: per-thread counts, workgroup scan, scatter of the first kcap ----
         int c = 0;
-        for (int p = p_lo; p < p_hi; ++p) {
-            const unsigned v = sc[p];
-            c += (v && v <= hi && (mask ? (v & mask) > prefix : true)) ? 1 : 0;
+        if constexpr (GK) {
+            for (int p0 = q_lo; p0 < q_hi; p0 += 256) {
+                unsigned v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int p = p0 + u * 64 + lane; v[u] = p < q_hi ? sc[p] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int p = p0 + u * 64 + lane; c += (p < q_hi && selected(v[u], p)) ? 1 : 0; }
+            }
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);     // every lane: this wave's count
+            if (lane == 0) wsum[wave] = c;
+        } else {
+            for (int p = p_lo; p < p_hi; ++p) c += selected(sc[p], p) ? 1 : 0;
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            c = incl - c;                                                  // exclusive prefix inside the wave
         }
-        int incl = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        int idx = incl - c;
+        int idx = GK ? 0 : c;
         for (int w = 0; w < wave; ++w) idx += wsum[w];
-        const int nsel = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (nsel == 0 || nsel > kcap) {                                    // >kcap candidates share one score
-            if (tid == 0) overflow[seg] = 1;
-            return;
-        }
-        for (int p = p_lo; p < p_hi; ++p) {
-            const unsigned v = sc[p];
-            if (v && v <= hi && (mask ? (v & mask) > prefix : true))
-                sk[idx++] = ((unsigned long long)v << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const int nsel = total < kcap ? total : kcap;                       // total > kcap only in tie mode
+        auto place = [&](unsigned v, int p, int at) {
+            if (at < kcap) sk[at] = ((unsigned long long)v << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+            else if (at == kcap) ctl[6] = p;                                // where the next tie chunk starts
+        };
+        if constexpr (GK) {
+            for (int p0 = q_lo; p0 < q_hi; p0 += 64) {
+                const int p = p0 + lane;
+                const unsigned v = p < q_hi ? sc[p] : 0u;
+                const bool s = p < q_hi && selected(v, p);
+                const unsigned long long m = __ballot(s);
+                if (s) place(v, p, idx + __popcll(m & ((1ull << lane) - 1ull)));
+                idx += __popcll(m);
+            }
+        } else {
+            for (int p = p_lo; p < p_hi; ++p) {
+                const unsigned v = sc[p];
+                if (selected(v, p)) place(v, p, idx++);
+            }
         }
         __syncthreads();
         DT_STAMP(stamps, 3);
@@ -525,7 +568,16 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
         DT_STAMP(stamps, 5);
         taken += nsel;
         if (nk >= top_k || taken >= n) break;
-        hi = prefix | ~mask;                                               // what is left lies at or below this chunk's bin
+        if (tie) {
+            if (total > kcap) {
+                tie_lo = ctl[6];
+            } else {                                                       // the tie group is used up
+                tie = false;
+                hi = tie_key - 1u;
+            }
+        } else {
+            hi = prefix | ~mask;                                           // what is left lies at or below this chunk's bin
+        }
         __syncthreads();
     }
     for (int i = nk * 5 + tid; i < top_k * 5; i += 256) orow[i] = 0.f;      // detection.py:39 zero-initialised output
@@ -533,50 +585,12 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
     DT_STAMP(stamps, 6);
 }
 
-// Second launch: segments flagged by the first are redone with every candidate in one sort (P-sized key
-// buffer); all other workgroups exit at once.
-__global__ __launch_bounds__(256) void detect_nms_kernel(const float *__restrict__ boxes, const float *__restrict__ sboxes,
-                                                         const float *__restrict__ scoresT, int P, int C, int top_k,
-                                                         float conf_thresh, NmsRule rule, int kcap,
-                                                         const int *__restrict__ overflow, float *__restrict__ out,
-                                                         int *__restrict__ counts_out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
-    unsigned long long *sk; void *kept_mem; int *ctl; unsigned char *alive_s; int *wsum; unsigned *unused;
-    detect_lds(dsm, kcap, top_k, sk, kept_mem, ctl, alive_s, wsum, unused);
-    const KeepList kept(kept_mem, top_k);
-    const int seg = blockIdx.x;
-    if (!overflow[seg]) return;
-    const int b = seg / C, lane = threadIdx.x & 63;
-    if (threadIdx.x < 2) ctl[threadIdx.x] = 0;
-    __syncthreads();
-    const float *row = scoresT + (size_t)seg * P;
-    for (int p0 = 0; p0 < P; p0 += 256) {
-        const int p = p0 + threadIdx.x;
-        const float s = p < P ? row[p] : 0.f;
-        const bool sel = p < P && s > conf_thresh;
-        const unsigned long long m = __ballot(sel);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&ctl[0], __popcll(m));
-        base = __shfl(base, 0, 64);
-        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (sel) sk[idx] = ((unsigned long long)score_key(s) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
-    }
-    __syncthreads();
-    float *orow = out + (size_t)seg * top_k * 5;
-    const int nk = sort_and_nms(sk, ctl[0], top_k, rule, kept, alive_s, ctl + 1, sboxes + (size_t)b * P * 4,
-                                boxes + (size_t)b * P * 4, orow, nullptr);
-    for (int i = nk * 5 + threadIdx.x; i < top_k * 5; i += 256) orow[i] = 0.f;
-    if (counts_out && threadIdx.x == 0) counts_out[seg] = nk;
-}
-
 static int next_pow2(int v) { int n = 64; while (n < v) n <<= 1; return n; }
 
 size_t detect_workspace_bytes(int B, int P, int C, int top_k)
 {
-    (void)top_k;   // boxes, boxes*scale, class-major scores, overflow flags
-    size_t n = align_up((size_t)B * P * 4 * sizeof(float), 256) * 2 + align_up((size_t)B * C * P * sizeof(float), 256) +
-               align_up((size_t)B * C * sizeof(int), 256);
+    (void)top_k;   // boxes, boxes*scale, class-major scores (overwritten by the score keys when P is large)
+    size_t n = align_up((size_t)B * P * 4 * sizeof(float), 256) * 2 + align_up((size_t)B * C * P * sizeof(float), 256);
 #ifdef TDRN_DETECT_TIMING
     n += (size_t)B * C * 8 * sizeof(long long);
 #endif
@@ -584,70 +598,76 @@ size_t detect_workspace_bytes(int B, int P, int C, int top_k)
 }
 
 int launch_detect(const float *loc, const float *conf, const float *priors, const float *arm_loc, const float *scale4,
-                  int B, int P, int C, int top_k, float conf_thresh, double nms_thresh, float *out, int32_t *counts_out,
-                  void *ws, size_t ws_bytes, hipStream_t s)
+                  int scale_on_device, int B, int P, int C, int top_k, float conf_thresh, double nms_thresh, float *out,
+                  int32_t *counts_out, void *ws, size_t ws_bytes, hipStream_t s)
 {
     if (!loc || !conf || !priors || !scale4 || !out || !ws) return TDRN_E_ARG;
+    if (scale_on_device && ((uintptr_t)scale4 & 15)) return TDRN_E_ARG;
     if (nms_thresh <= 0) return TDRN_E_VALUE;
     if (B <= 0 || P <= 0 || C < 2 || top_k <= 0) return TDRN_E_ARG;
     if (ws_bytes < detect_workspace_bytes(B, P, C, top_k)) return TDRN_E_WORKSPACE;
-    const int kcap_big = next_pow2(P);
 #ifndef TDRN_DET_KCAP
 #define TDRN_DET_KCAP 1024      // candidates per chunk: 1024 measured 6 % faster than 2048 (half the sort), 512 slower (second chunks)
 #endif
-    const int kcap_sel = kcap_big < TDRN_DET_KCAP ? kcap_big : TDRN_DET_KCAP;
-    const size_t lds_big = detect_lds_bytes(kcap_big, top_k);
-    const size_t lds_sel = detect_lds_bytes(kcap_sel, top_k) + 256 * 4 + (size_t)P * 4;
+    const int kcap_big = next_pow2(P);
+    const int kcap = kcap_big < TDRN_DET_KCAP ? kcap_big : TDRN_DET_KCAP;
+    const size_t lds_fixed = detect_lds_bytes(kcap, top_k);
     const size_t lds_dec = (size_t)256 * (C | 1) * sizeof(float);
-    if (lds_big > 160 * 1024 || lds_sel > 160 * 1024 || lds_dec > 160 * 1024) return TDRN_E_UNSUPPORTED;
+    constexpr size_t kLdsMax = 160 * 1024;
+    if (lds_fixed > kLdsMax || lds_dec > kLdsMax) return TDRN_E_UNSUPPORTED;       // top_k / class count beyond any caller's
+    const bool global_keys = lds_fixed + (size_t)P * 4 > kLdsMax;                  // P > ~37000
+    const size_t lds_sel = global_keys ? lds_fixed : lds_fixed + (size_t)P * 4;
     char *w = (char *)ws;
     float *boxes = (float *)w;   w += align_up((size_t)B * P * 4 * sizeof(float), 256);
     float *sboxes = (float *)w;  w += align_up((size_t)B * P * 4 * sizeof(float), 256);
     float *scoresT = (float *)w; w += align_up((size_t)B * C * P * sizeof(float), 256);
-    int *overflow = (int *)w;    w += align_up((size_t)B * C * sizeof(int), 256);
     long long *dbg = nullptr;
 #ifdef TDRN_DETECT_TIMING
     dbg = (long long *)w;
 #endif
     const NmsRule rule = make_rule(nms_thresh, 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_select_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TDRN_HIP_TRY(hipFuncSetAttribute((const void *)detect_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if (global_keys) TDRN_TRY(allow_big_lds((const void *)detect_select_nms_kernel<true>));
+    else TDRN_TRY(allow_big_lds((const void *)detect_select_nms_kernel<false>));
+    TDRN_TRY(allow_big_lds((const void *)detect_decode_kernel));
     const long long bp = (long long)B * P;
     hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((bp + 255) / 256)), dim3(256), lds_dec, s, loc, arm_loc, priors, conf,
-                       B, P, C, f32x4{scale4[0], scale4[1], scale4[2], scale4[3]}, boxes, sboxes, scoresT);
-    hipLaunchKernelGGL(detect_select_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_sel, s, boxes, sboxes, scoresT, P, C,
-                       top_k, conf_thresh, rule, kcap_sel, overflow, out, counts_out, dbg);
-    if (kcap_big > kcap_sel)
-        hipLaunchKernelGGL(detect_nms_kernel, dim3((unsigned)(B * C)), dim3(256), lds_big, s, boxes, sboxes, scoresT, P, C, top_k,
-                           conf_thresh, rule, kcap_big, overflow, out, counts_out);
+                       B, P, C, scale_on_device ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{scale4[0], scale4[1], scale4[2], scale4[3]},
+                       scale_on_device ? scale4 : (const float *)nullptr, boxes, sboxes, scoresT);
+    if (global_keys)
+        hipLaunchKernelGGL(detect_select_nms_kernel<true>, dim3((unsigned)(B * C)), dim3(256), lds_sel, s, boxes, sboxes, scoresT, P, C,
+                           top_k, conf_thresh, rule, kcap, out, counts_out, dbg);
+    else
+        hipLaunchKernelGGL(detect_select_nms_kernel<false>, dim3((unsigned)(B * C)), dim3(256), lds_sel, s, boxes, sboxes, scoresT, P, C,
+                           top_k, conf_thresh, rule, kcap, out, counts_out, dbg);
     return hip_status(hipGetLastError());
 }
 
 // ---- stand-alone NMS (cpu_nms / gpu_nms twins): one workgroup, keep list in global memory ------
+// sort key of box i: (score key | presorted: descending rank) : ~index
+__device__ __forceinline__ unsigned long long nms_key(const float *__restrict__ dets, int n, int presorted, int i)
+{
+    if (i >= n) return 0ull;
+    // presorted: keep the caller's order (gpu_nms.pyx:25-28 sorts on the host)
+    const unsigned hi = presorted ? (unsigned)(n - i) : score_key(dets[(size_t)i * 5 + 4]);
+    return ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+}
+
+// GK = false: the n <= 16384 keys are built and sorted in LDS.  GK = true: `gkeys` holds them, sorted, in global memory.
+template <bool GK>
 __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict__ dets, int n, NmsRule rule, int presorted,
+                                                        const unsigned long long *__restrict__ gkeys,
                                                         void *__restrict__ kept_mem, int *__restrict__ keep_out,
                                                         int *__restrict__ num_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
-    unsigned long long *sk = dsm;
-    int N = 64;
-    while (N < n) N <<= 1;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        unsigned long long k = 0ull;
-        if (i < n) {
-            // presorted: keep the caller's order (gpu_nms.pyx:25-28 sorts on the host)
-            const unsigned hi = presorted ? (unsigned)(n - i) : score_key(dets[(size_t)i * 5 + 4]);
-            k = ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-        }
-        sk[i] = k;
+    const unsigned long long *sk = GK ? gkeys : dsm;
+    if constexpr (!GK) {
+        int N = 64;
+        while (N < n) N <<= 1;
+        for (int i = threadIdx.x; i < N; i += 256) dsm[i] = nms_key(dets, n, presorted, i);
+        __syncthreads();
+        if (!presorted) bitonic_sort_desc(dsm, N, threadIdx.x, 256);
     }
-    __syncthreads();
-    if (!presorted) bitonic_sort_desc(sk, N, threadIdx.x, 256);
     if (threadIdx.x >= 64) return;
     const KeepList kept(kept_mem, n);
     const int nk = wave_greedy_nms(
@@ -662,7 +682,56 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict_
     if (threadIdx.x == 0) *num_out = nk;
 }
 
-size_t nms_workspace_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * sizeof(Box), 256); }
+// n > 16384 (the P = 92055 priors of multi_eval.py's 1216-pixel scale): the keys no longer fit LDS, so the bitonic
+// network runs over global memory: tiles of 4096 keys are sorted in LDS (directions by GLOBAL index, so that the
+// tiles come out as bitonic pairs), then per merge size kk the strides >= 4096 are one launch each and the strides
+// below that are finished tile by tile in LDS again.
+constexpr int kSortTile = 4096;
+__global__ __launch_bounds__(256) void nms_tile_sort_kernel(const float *__restrict__ dets, int n, int presorted, int do_sort,
+                                                            unsigned long long *__restrict__ keys)
+{
+    __shared__ unsigned long long t[kSortTile];
+    const int base = blockIdx.x * kSortTile;
+    for (int i = threadIdx.x; i < kSortTile; i += 256) t[i] = nms_key(dets, n, presorted, base + i);
+    __syncthreads();
+    if (do_sort)
+        for (int kk = 2; kk <= kSortTile; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                bitonic_stage(t, kSortTile, kk, j, threadIdx.x, 256, base);
+                __syncthreads();
+            }
+    for (int i = threadIdx.x; i < kSortTile; i += 256) keys[base + i] = t[i];
+}
+__global__ __launch_bounds__(256) void nms_global_stage_kernel(unsigned long long *__restrict__ keys, int N, int kk, int j)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (N >> 1)) return;
+    const int a = 2 * i - (i & (j - 1));
+    const unsigned long long x = keys[a], y = keys[a + j];
+    const bool desc = (a & kk) == 0;
+    if ((x < y) == desc) { keys[a] = y; keys[a + j] = x; }
+}
+__global__ __launch_bounds__(256) void nms_tile_merge_kernel(unsigned long long *__restrict__ keys, int kk)
+{
+    __shared__ unsigned long long t[kSortTile];
+    const int base = blockIdx.x * kSortTile;
+    for (int i = threadIdx.x; i < kSortTile; i += 256) t[i] = keys[base + i];
+    __syncthreads();
+    for (int j = kSortTile >> 1; j > 0; j >>= 1) {
+        bitonic_stage(t, kSortTile, kk, j, threadIdx.x, 256, base);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < kSortTile; i += 256) keys[base + i] = t[i];
+}
+
+constexpr int kNmsLdsKeys = 16384;      // 128 KiB of LDS sort keys
+static size_t nms_kept_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * sizeof(Box), 256); }
+size_t nms_workspace_bytes(int n)
+{
+    size_t b = nms_kept_bytes(n);
+    if (n > kNmsLdsKeys) b += (size_t)next_pow2(n) * sizeof(unsigned long long);
+    return b;
+}
 
 int launch_nms(const float *dets, int n, double thresh, int strict_gt, int presorted, int32_t *keep_out, int32_t *num_out,
                void *ws, size_t ws_bytes, hipStream_t s)
@@ -671,15 +740,25 @@ int launch_nms(const float *dets, int n, double thresh, int strict_gt, int preso
     if (n == 0) return hip_status(hipMemsetAsync(num_out, 0, sizeof(int), s));
     if (!dets || !keep_out || !ws) return TDRN_E_ARG;
     if (ws_bytes < nms_workspace_bytes(n)) return TDRN_E_WORKSPACE;
-    const int kcap = next_pow2(n);
-    if ((size_t)kcap * 8 > 128 * 1024) return TDRN_E_UNSUPPORTED;   // n <= 16384
+    const int N = next_pow2(n);
     const NmsRule rule = make_rule(thresh, strict_gt);
-    static bool attr_set = false;
-    if (!attr_set) {
-        TDRN_HIP_TRY(hipFuncSetAttribute((const void *)nms_plain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
+    if (n <= kNmsLdsKeys) {
+        TDRN_TRY(allow_big_lds((const void *)nms_plain_kernel<false>));
+        hipLaunchKernelGGL(nms_plain_kernel<false>, dim3(1), dim3(256), (size_t)N * 8, s, dets, n, rule, presorted,
+                           (const unsigned long long *)nullptr, ws, keep_out, num_out);
+        return hip_status(hipGetLastError());
     }
-    hipLaunchKernelGGL(nms_plain_kernel, dim3(1), dim3(256), (size_t)kcap * 8, s, dets, n, rule, presorted, ws, keep_out, num_out);
+    unsigned long long *keys = (unsigned long long *)((char *)ws + nms_kept_bytes(n));
+    const int tiles = N / kSortTile;
+    hipLaunchKernelGGL(nms_tile_sort_kernel, dim3(tiles), dim3(256), 0, s, dets, n, presorted, presorted ? 0 : 1, keys);
+    if (!presorted)
+        for (int kk = 2 * kSortTile; kk <= N; kk <<= 1) {
+            for (int j = kk >> 1; j >= kSortTile; j >>= 1)
+                hipLaunchKernelGGL(nms_global_stage_kernel, dim3(N / 512), dim3(256), 0, s, keys, N, kk, j);
+            hipLaunchKernelGGL(nms_tile_merge_kernel, dim3(tiles), dim3(256), 0, s, keys, kk);
+        }
+    hipLaunchKernelGGL(nms_plain_kernel<true>, dim3(1), dim3(256), 0, s, dets, n, rule, presorted, (const unsigned long long *)keys, ws,
+                       keep_out, num_out);
     return hip_status(hipGetLastError());
 }
 

@@ -8,6 +8,11 @@ namespace tdrn {
 // >= 256 zero bytes).  It lives at the start of the caller-provided workspace / weight blob.
 constexpr size_t kZeroPageBytes = 256;
 
+// Raises a kernel's dynamic-LDS limit to the full 160 KiB.  The attribute is per DEVICE: the call is repeated
+// for every device a kernel is used on (a small per-device, per-kernel memo keeps it off the hot path; it is
+// idempotent, so a race between threads only repeats the call).  (layers.hip)
+int allow_big_lds(const void *kernel);
+
 // ---------------------------------------------------------------------------------------------
 // Dense convolution as implicit GEMM on MFMA (conv_igemm.hip).
 //   in  : NHWC [B][H][W][Cin]      (DT; Cin a multiple of the 128-byte K-step)
@@ -120,7 +125,7 @@ int launch_decode(const float *loc, const float *priors, int P, float v0, float 
 int launch_center_size(const float *boxes, int P, float *out, hipStream_t s);
 size_t detect_workspace_bytes(int B, int P, int C, int top_k);
 int launch_detect(const float *loc, const float *conf, const float *priors, const float *arm_loc,
-                  const float *scale4, int B, int P, int C, int top_k, float conf_thresh,
+                  const float *scale4, int scale_on_device, int B, int P, int C, int top_k, float conf_thresh,
                   double nms_thresh, float *out, int32_t *counts, void *ws, size_t ws_bytes,
                   hipStream_t s);
 size_t nms_workspace_bytes(int n);

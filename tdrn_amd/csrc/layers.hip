@@ -5,6 +5,8 @@
 //   depthwise 3x3 + BN + ReLU model/networks.py:736-745
 //   Softmax(dim=1)            model/dualrefinedet_vggbn.py:116-117,196
 //   offset 1x1 convs          model/dualrefinedet_vggbn.py:53-57,71-76,155-164
+#include <atomic>
+
 #include "kernels.h"
 
 namespace tdrn {
@@ -739,6 +741,30 @@ int launch_preprocess(const unsigned char *in, int B, int H0, int W0, int S, con
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s)
 {
     return hip_status(hipMemsetAsync(p, 0, bytes, s));
+}
+
+int allow_big_lds(const void *kernel)
+{
+    constexpr int kSlots = 32;
+    static std::atomic<const void *> fn[kSlots];
+    static std::atomic<unsigned long long> done[kSlots];     // bit d: set on device d
+    int dev = 0;
+    TDRN_HIP_TRY(hipGetDevice(&dev));
+    int slot = -1;
+    for (int i = 0; i < kSlots && slot < 0; ++i) {
+        const void *cur = fn[i].load(std::memory_order_acquire);
+        if (cur == nullptr) {
+            const void *expect = nullptr;
+            if (fn[i].compare_exchange_strong(expect, kernel, std::memory_order_acq_rel)) cur = kernel;
+            else cur = expect;
+        }
+        if (cur == kernel) slot = i;
+    }
+    const bool memo = slot >= 0 && dev >= 0 && dev < 64;
+    if (memo && ((done[slot].load(std::memory_order_acquire) >> dev) & 1ull)) return TDRN_OK;
+    TDRN_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (memo) done[slot].fetch_or(1ull << dev, std::memory_order_release);
+    return TDRN_OK;
 }
 
 }  // namespace tdrn

@@ -867,6 +867,25 @@ struct tdrn_net {
             TDRN_TRY(init_lanes());
             TDRN_HIP_TRY(hipEventRecord(ev_fork, s0));
         }
+        // Whatever way this function is left -- also on a mid-plan error -- the caller's stream is ordered after
+        // everything already queued on the side lanes (they write the workspace and the outputs).
+        struct Join {
+            tdrn_net *n; hipStream_t s0; bool *used; bool on;
+            int run()
+            {
+                if (!on) return TDRN_OK;
+                on = false;
+                int rc = TDRN_OK;
+                for (int l = 1; l < kLanes; ++l)
+                    if (used[l]) {
+                        hipError_t e = hipEventRecord(n->ev_join[l - 1], n->side[l - 1]);
+                        if (e == hipSuccess) e = hipStreamWaitEvent(s0, n->ev_join[l - 1], 0);
+                        if (e != hipSuccess && rc == TDRN_OK) rc = (int)e;
+                    }
+                return rc;
+            }
+            ~Join() { (void)run(); }
+        } join{this, s0, lane_used, lanes};
         // split two-branch deformable heads accumulate into zeroed outputs: zero them on a side stream at the very
         // start (under the first conv) instead of in front of the deform launch on the critical path
         bool zeroed_early = false;
@@ -1043,13 +1062,7 @@ struct tdrn_net {
                 evi += 2;
             }
         }
-        if (lanes)
-            for (int l = 1; l < kLanes; ++l)
-                if (lane_used[l]) {
-                    TDRN_HIP_TRY(hipEventRecord(ev_join[l - 1], side[l - 1]));
-                    TDRN_HIP_TRY(hipStreamWaitEvent(s0, ev_join[l - 1], 0));
-                }
-        return TDRN_OK;
+        return join.run();
     }
 
     int collect_stats(tdrn_kernel_stat *out, int max_entries)

@@ -34,18 +34,28 @@ class Detect(object):
             raise ValueError("conf_data has %d rows, expected %d" % (conf.size(0), B * P))
         pri = prior_data.to(dev).contiguous().float()
         arm = arm_loc_data.contiguous().float() if arm_loc_data is not None else None
-        sc = [320.0] * 4 if scale is None else [float(v) for v in (scale.tolist() if hasattr(scale, "tolist") else scale)]
-        scale_h = (C.c_float * 4)(*sc)
         lib = _lib.lib()
+        # evaluate.py:461 passes a CUDA tensor: it is read on the device (no .tolist() = no hidden device sync)
+        scale_d = None
+        if isinstance(scale, torch.Tensor) and scale.is_cuda:
+            scale_d = scale.detach().to(dev, torch.float32).contiguous().view(-1)
+            if scale_d.numel() != 4:
+                raise ValueError("scale must have 4 elements")
+            if scale_d.data_ptr() % 16:
+                scale_d = scale_d.clone()
+        else:
+            sc = [320.0] * 4 if scale is None else [float(v) for v in (scale.tolist() if hasattr(scale, "tolist") else scale)]
+            scale_h = (C.c_float * 4)(*sc)
         nb = lib.tdrn_detect_workspace_bytes(B, P, Cn, self.top_k)
         if self._ws is None or self._ws.numel() < nb or self._ws.device != dev:
             self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         out = torch.empty((B, Cn, self.top_k, 5), dtype=torch.float32, device=dev)
         counts = torch.empty((B, Cn), dtype=torch.int32, device=dev)
-        _lib.check(lib.tdrn_detect(_lib.ptr(loc), _lib.ptr(conf), _lib.ptr(pri), _lib.ptr(arm), scale_h, B, P, Cn,
-                                   self.top_k, float(self.conf_thresh), float(self.nms_thresh), _lib.ptr(out),
-                                   _lib.ptr(counts), _lib.ptr(self._ws), self._ws.numel(),
-                                   _lib.current_stream(dev)), "tdrn_detect")
+        fn, sarg = (lib.tdrn_detect_dev_scale, _lib.ptr(scale_d)) if scale_d is not None else (lib.tdrn_detect, scale_h)
+        _lib.check(fn(_lib.ptr(loc), _lib.ptr(conf), _lib.ptr(pri), _lib.ptr(arm), sarg, B, P, Cn,
+                      self.top_k, float(self.conf_thresh), float(self.nms_thresh), _lib.ptr(out),
+                      _lib.ptr(counts), _lib.ptr(self._ws), self._ws.numel(),
+                      _lib.current_stream(dev)), "tdrn_detect")
         self.last_counts = counts
         return out
 

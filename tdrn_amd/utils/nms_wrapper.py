@@ -26,11 +26,13 @@ def cpu_nms(dets, thresh):
     return keep[: int(num.item())].cpu().tolist()
 
 
-def gpu_nms(dets, thresh, device_id=0):
+def gpu_nms(dets, thresh, device_id=None):
     dets = np.ascontiguousarray(dets, dtype=np.float32)
     n = dets.shape[0]
     if n == 0:
         return []
+    if device_id is None:          # the reference defaults to 0 (single-GPU scripts); a sharded rank uses its own GPU
+        device_id = torch.cuda.current_device()
     order = dets[:, 4].argsort()[::-1]
     sorted_dets = np.ascontiguousarray(dets[order, :])
     keep = np.zeros(n, dtype=np.int32)

@@ -7,8 +7,13 @@ it is copied.  Fixtures hold data only: seeds/inputs (or the recipe to regenerat
 tdrn_amd.utils.synth) and the reference's outputs.  The deformable op has no runnable reference
 (CUDA + THC only), so inside the reference model `model.networks.conv_offset2d` is patched to
 the oracle's restatement -- every other op in those forwards is the reference's
-own code.  The Cython cpu_nms is un-buildable (Cython 0.25 output vs Python 3.10): the
-reference's own pure-numpy twin utils/nms/py_cpu_nms.py pins the oracle's NMS instead.
+own code.  The Cython cpu_nms is un-buildable (Cython 0.25 output vs Python 3.10): the NMS that
+runs INSIDE the reference's Detect here is the reference's own pure-numpy twin
+utils/nms/py_cpu_nms.py (so no fixture is produced by the oracle's NMS).  That twin suppresses on
+IoU > thresh where cpu_nms.pyx:66 has >=; the two differ only at exact equality, and every Detect
+fixture asserts at generation time that swapping in the oracle's `>=` restatement changes nothing
+(no candidate pair sits exactly on the threshold).  The `>=` rule itself is pinned by the
+hand-built equality cases of tests/test_oracle_pin.py.
 """
 import os
 import sys
@@ -29,8 +34,27 @@ SUB = 4  # keep every SUB-th prior of the full-net outputs (fixture size)
 
 def main():
     import torch
-    ref = ref_shim.install(cpu_nms=lambda dets, thresh: orc.cpu_nms(dets, thresh))
+    ref = ref_shim.install()                       # utils.nms.cpu_nms.cpu_nms := the reference's py_cpu_nms
     torch.set_num_threads(8)
+    nms_wrapper = sys.modules["utils.nms_wrapper"]
+    ref_nms = nms_wrapper.cpu_nms
+
+    def detect_both(det, *a, strict=True, **k):
+        """Detect.forward with the reference's py_cpu_nms; asserts the oracle's >= twin gives the same rows.
+        strict=False (the nets' own random-init outputs, where some of the 6375 scores of a class collide in fp32):
+        numpy's unstable argsort()[::-1] orders equal scores differently from the oracle's stable lower-index-first
+        rule (SURVEY 8d "NMS tie caveat"), so only the fraction of identical rows is reported."""
+        o = det.forward(*a, **k)
+        nms_wrapper.cpu_nms = lambda dets, thresh: orc.cpu_nms(dets, thresh)
+        try:
+            o2 = det.forward(*a, **k)
+        finally:
+            nms_wrapper.cpu_nms = ref_nms
+        if strict:
+            assert torch.equal(o, o2), "py_cpu_nms and the oracle's cpu_nms disagree on tie-free input"
+        else:
+            print("   rows identical under both NMS twins: %.4f" % float((o == o2).all(-1).float().mean()))
+        return o
     out = {}
 
     # ---- PriorBox (layers/functions/prior_box.py) -------------------------------------------
@@ -74,9 +98,9 @@ def main():
         loc_d, arm_d, conf_d = synth.synth_detect_inputs(B, 6375, 21, bias, seed=1)
         det = ref["Detect"](21, 0, 200, 0.01, 0.45)
         scale = torch.tensor([500.0, 375.0, 500.0, 375.0])
-        o = det.forward(torch.from_numpy(loc_d), torch.from_numpy(conf_d), priors,
+        o = detect_both(det, torch.from_numpy(loc_d), torch.from_numpy(conf_d), priors,
                         arm_loc_data=torch.from_numpy(arm_d), scale=scale).numpy()
-        o_noarm = det.forward(torch.from_numpy(loc_d), torch.from_numpy(conf_d), priors,
+        o_noarm = detect_both(det, torch.from_numpy(loc_d), torch.from_numpy(conf_d), priors,
                               arm_loc_data=None, scale=torch.tensor([320.0] * 4)).numpy()
         np.savez_compressed(os.path.join(HERE, "detect_%s.npz" % tag), bias=bias, batch=B,
                             out=o, out_noarm=o_noarm)
@@ -109,8 +133,8 @@ def main():
                                                           (1024, 1, True, mh))
         P = arm_loc.shape[1]
         pri = ref["PriorBox"](ref["mb_cfg"]["VOC_%d" % size]).forward()
-        det = ref["Detect"](21, 0, 200, 0.01, 0.45).forward(
-            odm_loc, conf, pri, arm_loc_data=arm_loc, scale=torch.tensor([500., 375., 500., 375.]))
+        det = detect_both(ref["Detect"](21, 0, 200, 0.01, 0.45),
+                          odm_loc, conf, pri, arm_loc_data=arm_loc, scale=torch.tensor([500., 375., 500., 375.]), strict=False)
         np.savez_compressed(
             os.path.join(HERE, tag + ".npz"), sub=SUB, size=size, multihead=mh,
             keys=np.asarray(list(shapes.keys())),
@@ -122,6 +146,16 @@ def main():
             detect=det.numpy())
         print(tag, "arm|odm mean abs", float(arm_loc.abs().mean()), float(odm_loc.abs().mean()),
               "conf max", float(conf.max()), "dets", int((det[..., 0] > 0).sum()))
+    # ---- dualrefinedet_mobilenet (BASELINE config #4's model): multihead on / off -----------------
+    mob = {}
+    for tag, mh in (("mh", True), ("sh", False)):
+        net, shapes, (arm_loc, none, odm_loc, conf) = run("dualrefinedet_mobilenet", tag, 320, (1, mh), x_seed=23)
+        assert none is None
+        P = arm_loc.shape[1]
+        mob.update({tag + "_keys": np.asarray(list(shapes.keys())), tag + "_arm": arm_loc.numpy()[:, ::SUB],
+                    tag + "_odm": odm_loc.numpy()[:, ::SUB], tag + "_conf": conf.numpy().reshape(1, P, 21)[:, ::SUB]})
+        print("drn_mobilenet", tag, float(arm_loc.abs().mean()), float(odm_loc.abs().mean()), float(conf.max()))
+    np.savez_compressed(os.path.join(HERE, "drn_mobilenet_320.npz"), sub=SUB, x_seed=23, **mob)
     extra_models(ref, torch)
 
 

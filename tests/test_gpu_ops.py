@@ -235,6 +235,42 @@ def test_detect_selection_fallbacks_match_oracle():
     np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("cfg_name,dense", [("704", 5), ("1216", 2)])
+def test_detect_beyond_16384_priors_matches_oracle(cfg_name, dense):
+    """multi_eval.py:21-24 runs a 320-net at 704 pixels (P = 30855) and a 512-net at 1216 (P = 92055, where the
+    score keys no longer fit LDS and live in global memory).  `dense` classes have EVERY prior as a candidate,
+    one class is a single huge score tie (ascending prior index decides), the rest are sparse."""
+    from tdrn_amd.data import multi_cfg, multi_cfg_512
+    cfg = multi_cfg[cfg_name] if cfg_name in multi_cfg else multi_cfg_512[cfg_name]
+    pri = PriorBox(cfg).forward()
+    P = pri.shape[0]
+    assert P == {"704": 30855, "1216": 92055}[cfg_name]
+    loc, arm, conf = synth.synth_detect_inputs(1, P, 21, 9.0, seed=6)
+    conf = conf.copy()
+    rng = np.random.Generator(np.random.PCG64(12))
+    for c in range(1, 1 + dense):
+        conf[:, c] = (1.0 / 21 + 1e-3 * rng.standard_normal(P)).astype(np.float32)
+    conf[:, 1 + dense] = np.float32(0.04)                       # P-way tie
+    sc = [500.0, 375.0, 500.0, 375.0]
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    out = det.forward(_cu(loc), _cu(conf), pri.to(DEV), arm_loc_data=_cu(arm), scale=sc).cpu().numpy()
+    ref = orc.detect(loc, conf, pri.numpy(), arm, sc)
+    assert np.array_equal(out[..., 0], ref[..., 0])
+    np.testing.assert_allclose(out, ref, rtol=3e-6, atol=1e-6)
+    assert (det.last_counts.cpu().numpy()[0, 1:2 + dense] == 200).all()
+
+
+def test_nms_beyond_16384_boxes_matches_oracle():
+    """n > 16384: the sort keys leave LDS (global bitonic network); keep lists stay bit-exact, both rules."""
+    for n, spread, seed in ((16385, 400, 3), (40000, 700, 4)):
+        dets = _random_dets(n, spread, seed)
+        assert len(np.unique(dets[:, 4])) == n
+        for strict in (False, True):
+            ref = orc.cpu_nms(dets, 0.45, strict_gt=strict)
+            got = nms(dets, 0.45, force_cpu=not strict)
+            assert got == ref
+
+
 def test_detect_coco_class_count_matches_oracle():
     """81 classes (COCO, data/config.py COCO_300): the score transpose tile and the per-(image, class) grid at
     a class count other than 21; D8-like regime plus one dense class."""

@@ -183,6 +183,23 @@ def _shapes(modname, args):
     return {k: tuple(v.shape) for k, v in net.state_dict().items()}
 
 
+@pytest.mark.parametrize("tag,mh", [("mh", True), ("sh", False)])
+def test_drn_mobilenet_restatement_matches_reference(golden_dir, tag, mh):
+    """BASELINE config #4's model: oracle/net_ref.drn_mobilenet_forward vs the reference's own
+    model/dualrefinedet_mobilenet.py:127-199 forward (deformable op patched to the oracle), multihead on / off."""
+    g = _g(golden_dir, "drn_mobilenet_320.npz")
+    sub = int(g["sub"])
+    sh = _shapes("dualrefinedet_mobilenet", (320, 21, 1, mh))
+    assert sorted(sh) == sorted(str(k) for k in g[tag + "_keys"])
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    x = synth.synth_frames(1, 320, int(g["x_seed"]))
+    arm, none, odm, conf = net_ref.drn_mobilenet_forward(synth.synth_state_dict(sh, 0), x, 21, mh)
+    assert none is None
+    np.testing.assert_allclose(arm.numpy()[:, ::sub], g[tag + "_arm"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(odm.numpy()[:, ::sub], g[tag + "_odm"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conf.numpy().reshape(1, -1, 21)[:, ::sub], g[tag + "_conf"], rtol=1e-4, atol=5e-5)
+
+
 def test_other_model_restatements_match_reference(golden_dir):
     """refinedet_vgg (the reference's own CPU forward, no patched op at all), ssd4scale_vgg / _mobile static
     and temporal (TRN) nets: oracle/net_ref.py vs tests/golden/other_models.npz."""
