@@ -197,15 +197,47 @@ def mobilenet_trunk(sd, x):
     return outs
 
 
-def drn_mobilenet_forward(sd, x, num_classes=21, multihead=False, phase="test", def_groups=1):
+def drn_mobilenet_forward(sd, x, num_classes=21, multihead=False, phase="test", def_groups=1, taps=None):
     """model/dualrefinedet_mobilenet.py:127-199."""
     x = torch.as_tensor(x)
     with torch.no_grad():
         a, b, c, d = mobilenet_trunk(sd, x)
         srcs = [_l2norm(sd, "L2Norm_4_3", a), _l2norm(sd, "L2Norm_5_3", b), c, d]
         arm_loc, _, odm_loc, conf = _drn_head(sd, srcs, d, num_classes, multihead, phase,
-                                              def_groups)
+                                              def_groups, taps)
         return arm_loc, None, odm_loc, conf
+
+
+def border_rows(taps, multihead, eps=1e-4, def_groups=1):
+    """Which prior rows of (odm_loc, conf) may legitimately differ between two fp32 implementations.
+
+    The reference's sampling rule is DISCONTINUOUS where a sample coordinate crosses 0 or the map size
+    (deform_conv_cuda_kernel.cu:195: h_im < 0 or h_im >= H -> 0; just inside -> the border pixel's full value), so
+    an offset that differs in its last bits flips one output pixel by O(1).  From the ORACLE's offsets
+    (taps["offset.<s>"] = [offset ; offset2] of _drn_head) this returns a boolean mask over the B*P prior rows
+    (scale-major, then pixel, then anchor) marking the pixels for which some tap of some branch samples within
+    `eps` of such a discontinuity; every other row must meet the plain tolerance."""
+    masks = []
+    s = 0
+    while ("offset.%d" % s) in taps:
+        off = taps["offset.%d" % s].double().numpy()
+        B, _, H, W = off.shape
+        hh = np.arange(H, dtype=np.float64).reshape(1, H, 1)
+        ww = np.arange(W, dtype=np.float64).reshape(1, 1, W)
+        near = np.zeros((B, H, W), bool)
+        c0 = 0
+        for k, pad in ((3, 1), (5, 2)) if multihead else ((3, 1),):
+            for g in range(def_groups):
+                for i in range(k):
+                    for j in range(k):
+                        ch = c0 + g * 2 * k * k + 2 * (i * k + j)
+                        h_im = hh - pad + i + off[:, ch]
+                        w_im = ww - pad + j + off[:, ch + 1]
+                        near |= (np.abs(h_im) < eps) | (np.abs(h_im - H) < eps) | (np.abs(w_im) < eps) | (np.abs(w_im - W) < eps)
+            c0 += def_groups * 2 * k * k
+        masks.append(np.repeat(near.reshape(B, H * W), 3, axis=1))        # 3 anchors per pixel
+        s += 1
+    return np.concatenate(masks, axis=1).reshape(-1)
 
 
 def _ssd4scale_heads(sd, srcs, x, num_classes, phase, deform_on, ref_loc, offset_list, ret_loc, ret_off):

@@ -1,0 +1,140 @@
+"""Per-stage drift of the 16-bit compute modes against the fp32 CPU oracle (checker only; run on the GPU box).
+
+    python scripts/drift_table.py [--out profiles/r02_drift]
+
+Writes
+  stages_<dtype>.csv : every internal activation of dualrefinedet_vggbn-320 (multihead) the oracle also exposes:
+                       max / mean |hip - oracle|, mean |oracle|, relative mean error -- for fp32, bf16, fp16
+  families.csv       : final outputs (arm_loc, odm_loc / loc, conf, decoded boxes) of every model family per dtype:
+                       mean, 99.9th percentile and max abs error (the deformable border rule makes the max
+                       meaningless behind the heads), plus box L-inf of the decoded boxes
+The numbers justify the headline dtype choice and set tests/test_gpu_net.py:DRIFT_BOUNDS (<= 1.5x measured).
+"""
+import argparse
+import csv
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle import net_ref
+from oracle import oracle as orc
+from tdrn_amd.data import mb_cfg
+from tdrn_amd.utils import synth
+
+DEV = "cuda:0"
+
+
+def build(mod, args, seed=0):
+    net = importlib.import_module("tdrn_amd.model." + mod).build_net("test", *args)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.eval().to(DEV), sd
+
+
+def err(got, ref, exclude_rows=None):
+    """mean / p99.9 / max of |got - ref|.  exclude_rows (bool per prior row): rows of pixels with a deformable tap
+    near a sampling discontinuity, left out of p99.9 and max (they flip by O(1) in ANY reduced precision)."""
+    e = (torch.as_tensor(got).float().cpu() - torch.as_tensor(ref).float()).abs()
+    mean = float(e.mean())
+    if exclude_rows is not None:
+        e = e.reshape(len(exclude_rows), -1)[torch.from_numpy(~exclude_rows)]
+    e = e.flatten()
+    q = float(torch.quantile(e[:: max(1, e.numel() // 4000000)], 0.999))
+    return mean, q, float(e.max())
+
+
+# offsets drift by up to 1.2e-2 (bf16) / 1.5e-3 (fp16) pixels (stages_*.csv, offset.*): pixels with a tap closer than ~2.5x that
+# to a sampling discontinuity are reported separately
+NEAR_EPS = {"fp32": 1e-4, "bf16": 0.03, "fp16": 0.004}
+
+
+def decoded(arm, loc, pri):
+    """two-stage decode of layers/box_utils.py:176-195 with the oracle (normalised boxes)."""
+    out = []
+    for b in range(loc.shape[0]):
+        anchors = pri
+        if arm is not None:
+            anchors = orc.center_size(orc.decode(np.ascontiguousarray(arm[b]), pri))
+        out.append(orc.decode(np.ascontiguousarray(loc[b]), anchors))
+    return np.stack(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="profiles/r02_drift")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    pri = orc.prior_box(mb_cfg["VOC_320"])
+
+    # ---- per-stage table, primary model -------------------------------------------------------------------
+    net, sd = build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    x = synth.synth_frames(1, 320, seed=5)
+    taps = {}
+    ref = net_ref.drn_vggbn_forward(sd, x, 21, True, True, taps=taps)
+    for dt in ("fp32", "bf16", "fp16"):
+        net.set_compute_dtype(dt)
+        net(torch.from_numpy(x).to(DEV))
+        eng = net._engine
+        with open(os.path.join(args.out, "stages_%s.csv" % dt), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["stage", "max_abs_err", "mean_abs_err", "mean_abs_ref", "rel_mean_err"])
+            for i, (label, c, h, wd) in enumerate(eng.tensor_infos()):
+                if label in taps:
+                    got = eng.read_tensor(i, 1).cpu()
+                    r = taps[label]
+                    if tuple(got.shape) != tuple(r.shape):
+                        continue
+                    m, _, mx = err(got, r)
+                    ra = float(r.abs().mean())
+                    w.writerow([label, "%.3e" % mx, "%.3e" % m, "%.3e" % ra, "%.3e" % (m / max(ra, 1e-30))])
+
+    # ---- final outputs of every family --------------------------------------------------------------------
+    rows = [["family", "dtype", "output", "mean_abs_err", "p99.9_abs_err", "max_abs_err", "mean_abs_ref", "rows_near_discontinuity"]]
+    fams = [
+        ("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True), lambda sd, x, taps: net_ref.drn_vggbn_forward(sd, x, 21, True, True, taps=taps)),
+        ("dualrefinedet_mobilenet", (320, 21, 1, True), lambda sd, x, taps: net_ref.drn_mobilenet_forward(sd, x, 21, True, taps=taps)),
+        ("refinedet_vgg", (320, 21, True, 1024, True, True), lambda sd, x, taps: net_ref.refinedet_vgg_forward(sd, x, 21, True, True, True)),
+        ("ssd4scale_vgg", (320, 21, 1024, True, False), lambda sd, x, taps: net_ref.ssd4scale_vgg_forward(sd, x, 21, "test", True)),
+        ("ssd4scale_mobile", (320, 21, 1024, False), lambda sd, x, taps: net_ref.ssd4scale_mobile_forward(sd, x, 21, "test")),
+    ]
+    for mod, a, fwd in fams:
+        net, sd = build(mod, a)
+        x = synth.synth_frames(1, 320, seed=5)
+        taps = {}
+        r = fwd(sd, x, taps)
+        if len(r) == 4:
+            r_arm, r_loc, r_conf = r[0], r[2], r[3]
+        else:
+            r_arm, r_loc, r_conf = None, r[0], r[1]
+        r_box = decoded(None if r_arm is None else r_arm.numpy(), r_loc.numpy(), pri)
+        for dt in ("fp32", "bf16", "fp16"):
+            net.set_compute_dtype(dt)
+            o = net(torch.from_numpy(x).to(DEV))
+            if len(o) == 4:
+                arm, loc, conf = o[0], o[2], o[3]
+            else:
+                arm, loc, conf = None, o[0], o[1]
+            box = decoded(None if arm is None else arm.cpu().numpy(), loc.cpu().numpy(), pri)
+            items = [("loc" if arm is None else "odm_loc", loc, r_loc), ("conf", conf, r_conf.reshape(conf.shape)),
+                     ("decoded_boxes", torch.from_numpy(box), torch.from_numpy(r_box))]
+            if arm is not None:
+                items.insert(0, ("arm_loc", arm, r_arm))
+            near = net_ref.border_rows(taps, True, NEAR_EPS[dt]) if taps else None
+            for name, g, rr in items:
+                ex = near if (near is not None and name != "arm_loc") else None
+                m, q, mx = err(g, rr, ex)
+                rows.append([mod, dt, name, "%.3e" % m, "%.3e" % q, "%.3e" % mx, "%.3e" % float(torch.as_tensor(rr).abs().mean()),
+                             int(ex.sum()) if ex is not None else 0])
+    with open(os.path.join(args.out, "families.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    for r in rows:
+        print(",".join(str(v) for v in r))
+
+
+if __name__ == "__main__":
+    main()
