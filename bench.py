@@ -11,8 +11,10 @@ runs its own batch (frames shard, weights arrive by one RCCL broadcast, no per-f
 weak scaling, value = all ranks' frames / max-over-ranks time.
 
 The JSON line also carries
-  roofline     : the dominant kernel (conv_igemm_mfma): algorithmic FLOPs of its launches in one
+  roofline     : the dominant kernel family (conv3x3_patch_mfma): algorithmic FLOPs of its launches in one
                  step / their summed hipEvent durations, against the dense bf16 MFMA peak
+  parity       : the other half of BASELINE's metric ("box L-inf vs CPU ref"): decoded boxes and softmax scores of
+                 the TIMED dtype (and of the fp32 and fp16 modes beside it) against the fp32 CPU oracle on one frame
   cpu_baseline : the CPU oracle (torch-CPU convs + C deformable conv + C Detect) on a bounded sample
                  of the same workload on this host's cores (rank 0, N=1 only)
 """
@@ -41,6 +43,50 @@ def pmc_traffic(kernel, args):
         return e["hbm_bytes_per_launch"] if e else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+NEAR_EPS = {"fp32": 1e-4, "bf16": 0.03, "fp16": 0.004}   # pixels with a deformable tap this close to a sampling discontinuity
+
+
+def parity_vs_oracle(size, dtypes, dev):
+    """Box / score error of the HIP path in each of `dtypes` against the fp32 CPU oracle on one synthetic frame.
+    Boxes = two-stage decode (layers/box_utils.py:176-195, what Detect does first) of (arm_loc, odm_loc) in normalised
+    image coordinates.  The deformable sampling rule is discontinuous at the map border
+    (deform_conv_cuda_kernel.cu:195), so prior rows of pixels with a tap within NEAR_EPS of it flip by O(1) in ANY
+    implementation that rounds differently; they are counted and left out of the L-inf / p99.9 (not of the mean)."""
+    import numpy as np
+    import torch
+    from oracle import net_ref
+    from oracle import oracle as orc
+    from tdrn_amd.layers.box_utils import center_size, decode
+    from tdrn_amd.model.dualrefinedet_vggbn import build_net
+    from tdrn_amd.utils import synth
+    net = build_net("test", size, 21, 1024, 1, True, True)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    x = synth.synth_frames(1, size, seed=5)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    taps = {}
+    r_arm, _, r_odm, r_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, True, taps=taps)
+    cfg = dict(feature_maps=[size // 8, size // 16, size // 32, size // 64], min_dim=size, steps=[8, 16, 32, 64],
+               min_sizes=[32, 64, 128, 256], max_sizes=[], aspect_ratios=[[2]] * 4, variance=[0.1, 0.2], clip=True,
+               flip=True, name="bench")
+    pri = orc.prior_box(cfg)
+    r_box = orc.decode(r_odm.numpy()[0], orc.center_size(orc.decode(r_arm.numpy()[0], pri)))
+    out = {"frames": 1, "reference": "fp32 CPU oracle (oracle/net_ref.py + oracle/tdrn_oracle.c)", "box_unit": "normalised image coordinates"}
+    pri_d = torch.from_numpy(pri).to(dev)
+    for dt in dtypes:
+        net.set_compute_dtype(dt)
+        arm, _, odm, conf = net(torch.from_numpy(x).to(dev))
+        box = decode(odm[0], center_size(decode(arm[0], pri_d, [0.1, 0.2])), [0.1, 0.2]).cpu().numpy()   # tdrn_decode / tdrn_center_size
+        near = net_ref.border_rows(taps, True, NEAR_EPS[dt])
+        eb = np.abs(box - r_box)
+        es = np.abs(conf.cpu().numpy() - r_conf.numpy().reshape(conf.shape))
+        out[dt] = {"box_linf": float(eb[~near].max()), "box_p999": float(np.quantile(eb[~near], 0.999)), "box_mean": float(eb.mean()),
+                   "score_linf": float(es[~near].max()), "score_mean": float(es.mean()),
+                   "rows_near_discontinuity": int(near.sum()), "box_linf_all_rows": float(eb.max())}
+    return out
 
 
 def cpu_baseline(size, frames=2):
@@ -83,6 +129,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the box / score error block (one oracle forward on the host)")
     ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=96)      # ~16 s of CPU work on the GPU box host
@@ -203,6 +250,11 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if not args.no_parity:
+            par = parity_vs_oracle(args.size, [args.dtype] + [d for d in ("fp32", "fp16") if d != args.dtype], dev)
+            line["parity"] = par
+            line["box_linf"] = par[args.dtype]["box_linf"]              # the timed dtype's figure; fp32 mode: par["fp32"]
+            line["score_linf"] = par[args.dtype]["score_linf"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_frames)
         print(json.dumps(line))

@@ -1,0 +1,68 @@
+"""The multi-GPU path exercised on ONE GPU: two fresh processes (spawned before anything touches the
+GPU) share cuda:0 over the gloo backend -- rank 0 packs the weights, rank 1 receives the blob through
+EngineModule.adopt_broadcast_weights / NetEngine.broadcast_weights and never sees the checkpoint -- and `bench.py
+--gpus 2` runs its N > 1 branch (tdist.init, barrier, max-over-ranks timing, whole-job value) the same way.  On a
+real node the backend is RCCL and every rank has its own GPU; the code path is the same."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(argv, world=2, timeout=600):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TDRN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o.decode(), e.decode()))
+    for rc, o, e in outs:
+        assert rc == 0, "rank failed (rc %d):\n%s\n%s" % (rc, o[-2000:], e[-4000:])
+    return outs
+
+
+def test_broadcast_weights_two_ranks_one_gpu(tmp_path):
+    _launch([os.path.join(ROOT, "tests", "_dist_worker.py"), str(tmp_path)])
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert r0["wsum"][0] == r1["wsum"][0] and r0["wsum"][0] != 0.0          # the same packed blob on both ranks
+    for k in ("arm", "odm", "conf"):
+        assert np.array_equal(r0[k], r1[k]), k                                # rank 1 never loaded a state_dict
+    # frame sharding: contiguous halves, each equal to the corresponding rows of the full batch
+    assert r0["shard"].tolist() == [0, 2] and r1["shard"].tolist() == [2, 4]
+    assert np.array_equal(r0["shard_odm"], r0["odm"][0:2]) and np.array_equal(r1["shard_odm"], r0["odm"][2:4])
+
+
+def test_bench_py_two_ranks_one_gpu():
+    outs = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4",
+                    "--no-cpu-baseline"])
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][1].splitlines() if l.startswith("{")]    # rank 0 prints the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert abs(d["value"] - 2 * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3            # whole-job frames / max-over-ranks time
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0

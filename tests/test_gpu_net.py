@@ -112,31 +112,69 @@ def test_drn_vggbn_matches_reference_golden(golden_dir, tag, mh):
     np.testing.assert_allclose(det, mine, rtol=3e-6, atol=1e-6)
 
 
-DRIFT_BOUNDS = {   # (mean, 99.9th percentile) of |hip - fp32 oracle|; measured r01: bf16 odm (0.016, 0.30), fp16 odm (0.002, 0.016..0.065:
-                   # the p99.9 is set by the 2-3 border pixels whose offsets cross the sampling discontinuity, which moves with the summation order)
-    "bf16": {"arm": (0.01, 0.12), "odm": (0.035, 0.5), "conf": (0.006, 0.12)},
-    "fp16": {"arm": (0.001, 0.015), "odm": (0.006, 0.15), "conf": (0.0006, 0.012)},
+# Measured drift of the 16-bit modes vs the fp32 oracle (scripts/drift_table.py on frame seed 5 -> profiles/r02_drift/families.csv):
+# (mean over everything, 99.9th percentile over the prior rows AWAY from a sampling discontinuity).  The deformable
+# sampling rule is discontinuous at the map border (deform_conv_cuda_kernel.cu:195), so pixels with a tap within
+# NEAR_EPS of it -- 2.5x the measured offset drift of the dtype -- flip by O(1) in ANY reduced precision; they are
+# excluded from the percentile (not from the mean) and counted.  The tests allow 1.5x these numbers.  The error
+# grows smoothly with depth (profiles/r02_drift/stages_*.csv: 0.14 % after conv1_1 to 1.1 % at the end of the FPN in
+# bf16, 8x less in fp16): it is the input rounding of every layer, not one bad kernel.
+NEAR_EPS = {"bf16": 0.03, "fp16": 0.004}
+DRIFT_MEASURED = {
+    ("dualrefinedet_vggbn", "bf16"): {"arm": (2.357e-3, 4.441e-2), "odm": (1.633e-2, 1.013e-1), "conf": (8.856e-4, 3.134e-2)},
+    ("dualrefinedet_vggbn", "fp16"): {"arm": (2.902e-4, 5.343e-3), "odm": (2.103e-3, 1.218e-2), "conf": (1.148e-4, 3.926e-3)},
+    ("dualrefinedet_mobilenet", "bf16"): {"arm": (4.907e-3, 1.508e-1), "odm": (5.800e-2, 9.604e-1), "conf": (1.551e-3, 1.244e-1)},
+    ("dualrefinedet_mobilenet", "fp16"): {"arm": (6.172e-4, 1.854e-2), "odm": (8.341e-3, 1.059e-1), "conf": (2.261e-4, 1.603e-2)},
+    ("refinedet_vgg", "bf16"): {"arm": (2.357e-3, 4.441e-2), "odm": (1.819e-2, 8.462e-2), "conf": (8.577e-4, 3.514e-2)},
+    ("refinedet_vgg", "fp16"): {"arm": (2.902e-4, 5.343e-3), "odm": (2.396e-3, 1.161e-2), "conf": (1.117e-4, 4.649e-3)},
+    ("ssd4scale_vgg", "bf16"): {"arm": (2.357e-3, 4.441e-2), "conf": (1.022e-4, 4.810e-3)},
+    ("ssd4scale_vgg", "fp16"): {"arm": (2.902e-4, 5.343e-3), "conf": (1.271e-5, 6.316e-4)},
+    ("ssd4scale_mobile", "bf16"): {"arm": (4.907e-3, 1.508e-1), "conf": (1.596e-4, 1.597e-2)},
+    ("ssd4scale_mobile", "fp16"): {"arm": (6.172e-4, 1.854e-2), "conf": (2.016e-5, 1.830e-3)},
+}
+FAMILIES = {   # build_net args (after phase) and the oracle forward -> (arm_loc | loc, odm_loc | None, conf)
+    "dualrefinedet_vggbn": ((320, 21, 1024, 1, True, True), lambda sd, x, taps: net_ref.drn_vggbn_forward(sd, x, 21, True, True, taps=taps)),
+    "dualrefinedet_mobilenet": ((320, 21, 1, True), lambda sd, x, taps: net_ref.drn_mobilenet_forward(sd, x, 21, True, taps=taps)),
+    "refinedet_vgg": ((320, 21, True, 1024, True, True), lambda sd, x, taps: net_ref.refinedet_vgg_forward(sd, x, 21, True, True, True)),
+    "ssd4scale_vgg": ((320, 21, 1024, True, False), lambda sd, x, taps: net_ref.ssd4scale_vgg_forward(sd, x, 21, "test", True)),
+    "ssd4scale_mobile": ((320, 21, 1024, False), lambda sd, x, taps: net_ref.ssd4scale_mobile_forward(sd, x, 21, "test")),
 }
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_drn_vggbn_16bit_drift_is_bounded(dtype):
-    """bf16/fp16 drift is reported separately from the 1e-3 fp32 claim.  The
-    deformable sampling rule is discontinuous at the top/left border (a coordinate of -0.001 gives 0,
-    +0.001 the full value: deform_conv_cuda_kernel.cu:195), so a handful of ODM outputs can move by
-    O(1) when 16-bit offsets cross it; the bound is therefore on the mean and the 99.9th percentile."""
-    net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
-    net.set_compute_dtype(dtype)
-    x = synth.synth_frames(1, 320, seed=5)
-    ref_arm, _, ref_odm, ref_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, True)
-    arm, _, odm, conf = net(torch.from_numpy(x).to(DEV))
+def _split_outputs(o):
+    return (o[0], o[2], o[3]) if len(o) == 4 else (o[0], None, o[1])
+
+
+def _check_drift(family, dtype, net, sd, x):
+    """Runs `net` (already in `dtype`) on frame(s) x and checks its drift against 1.5x DRIFT_MEASURED[(family, dtype)]."""
+    taps = {}
+    r_arm, r_odm, r_conf = _split_outputs(FAMILIES[family][1](sd, x, taps))
+    arm, odm, conf = _split_outputs(net(torch.from_numpy(x).to(DEV)))
+    near = net_ref.border_rows(taps, True, NEAR_EPS[dtype]) if taps else None
     rep = {}
-    for name, got, ref in (("arm", arm, ref_arm), ("odm", odm, ref_odm), ("conf", conf, ref_conf)):
-        e = (got.cpu() - ref).abs().flatten()
-        rep[name] = (float(e.mean()), float(torch.quantile(e, 0.999)), float(e.max()))
-    print("%s drift (mean, p99.9, max): %r" % (dtype, rep))
-    for name, (m, q) in DRIFT_BOUNDS[dtype].items():
-        assert rep[name][0] < m and rep[name][1] < q, (name, rep[name])
+    for name, got, ref in (("arm", arm, r_arm), ("odm", odm, r_odm), ("conf", conf, r_conf)):
+        if got is None:
+            continue
+        e = (got.cpu() - ref.reshape(got.shape)).abs()
+        away = e.reshape(-1, e.shape[-1])
+        if near is not None and name != "arm":
+            away = away[torch.from_numpy(~near)]
+        rep[name] = (float(e.mean()), float(torch.quantile(away.flatten()[:: max(1, away.numel() // 4000000)], 0.999)))
+    print("%s %s drift (mean, p99.9 away from discontinuities): %r; rows near: %d" % (family, dtype, rep, 0 if near is None else int(near.sum())))
+    for name, (m, q) in DRIFT_MEASURED[(family, dtype)].items():
+        assert rep[name][0] < 1.5 * m and rep[name][1] < 1.5 * q, (family, dtype, name, rep[name], (m, q))
+    if near is not None:
+        assert near.mean() < 0.25
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_16bit_drift_is_bounded(family, dtype):
+    """bf16/fp16 drift of every model family is reported separately from the 1e-3 fp32 claim and held
+    to 1.5x the committed measurement."""
+    net, sd = _build(family, FAMILIES[family][0])
+    net.set_compute_dtype(dtype)
+    _check_drift(family, dtype, net, sd, synth.synth_frames(1, 320, seed=5))
 
 
 def test_batch32_rows_equal_single_frame_runs():
@@ -214,6 +252,92 @@ def test_ssd4scale_mobile_static_and_temporal_nets():
     det = Detect(21, 0, 200, 0.01, 0.45).forward(loc, conf, pri).cpu().numpy()
     ref = orc.detect(loc.cpu().numpy(), conf.cpu().numpy(), pri.cpu().numpy(), None, (320,) * 4)
     assert np.array_equal(det[..., 0], ref[..., 0])
+
+
+def _rows_equal_single_runs(net, x, rows, unpack=_split_outputs):
+    full = unpack(net(x))
+    B = x.size(0)
+    for t in full:
+        assert t is None or bool(torch.isfinite(t).all())
+    for b in rows:
+        one = unpack(net(x[b:b + 1]))
+        for f, o in zip(full, one):
+            if f is None:
+                continue
+            f = f.view(B, -1, f.shape[-1])
+            assert torch.equal(f[b], o.view(1, -1, o.shape[-1])[0]), "batch row %d differs from the single-frame run" % b
+    return full
+
+
+def test_config3_vggbn_512_fp16_batch16():
+    """BASELINE config #3 at its stated size: 512x512, fp16, batch 16, deformable path on.  Every frame's outputs
+    are bit-identical to running it alone; Detect on the batch equals the oracle's Detect on the same outputs."""
+    net, sd = _build("dualrefinedet_vggbn", (512, 21, 1024, 1, True, True))
+    net.half()
+    x = torch.from_numpy(synth.synth_frames(16, 512, seed=33)).to(DEV)
+    arm, odm, conf = _rows_equal_single_runs(net, x, (0, 9, 15))
+    assert arm.shape == (16, 16320, 4) and conf.shape == (16 * 16320, 21)
+    pri = PriorBox(mb_cfg["VOC_512_RefineDet"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45).forward(odm, conf, pri, arm_loc_data=arm).cpu().numpy()
+    b = 11
+    mine = orc.detect(odm[b:b + 1].cpu().numpy(), conf.view(16, 16320, 21)[b].cpu().numpy(), pri.cpu().numpy(),
+                      arm[b:b + 1].cpu().numpy(), (320,) * 4)
+    assert np.array_equal(det[b][..., 0], mine[0][..., 0])
+
+
+def test_config4_drn_mobilenet_bf16_batch64():
+    """BASELINE config #4's per-GPU workload: dualrefinedet_mobilenet 320, batch 64, bf16 (the depthwise strip
+    kernel in its 16-bit form): batch rows == single-frame runs bit for bit, drift of one frame within the table."""
+    net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True))
+    net.bfloat16()
+    x = torch.from_numpy(synth.synth_frames(64, 320, seed=35)).to(DEV)
+    arm, odm, conf = _rows_equal_single_runs(net, x, (0, 33, 63))
+    assert arm.shape == (64, 6375, 4) and conf.shape == (64 * 6375, 21)
+    _check_drift("dualrefinedet_mobilenet", "bf16", net, sd, synth.synth_frames(1, 320, seed=5))
+
+
+def test_config5_trn_8_clips_of_4_frames():
+    """BASELINE config #5: the TRN temporal path on 8 clips x 4 frames (evaluate_trn.py:438-467 batched over clips):
+    key frame -> static net (loc maps) -> temporal net (offsets), the three following frames reuse the cached
+    offsets.  Every clip's results are bit-identical to running that clip alone; the fp32 key-frame pass of one
+    clip matches the oracle.  refinedet_vgg (the model the config names) at batch 8 likewise."""
+    stat, sd_s = _build("ssd4scale_vgg", (320, 21, 1024, True, False), seed=0)
+    temp, sd_t = _build("ssd4scale_vgg", (320, 21, 1024, True, True), seed=1)
+    clips = torch.from_numpy(synth.synth_frames(32, 320, seed=37)).to(DEV).view(8, 4, 3, 320, 320)
+
+    def run(cl, dtype):
+        for n in (stat, temp):
+            if n.compute_dtype != dtype:
+                n.set_compute_dtype(dtype)
+        s_loc, s_conf, maps = stat(cl[:, 0].contiguous(), ret_loc=True)
+        outs = [temp(cl[:, 0].contiguous(), ref_loc=maps, ret_off=True)]
+        for f in range(1, 4):
+            outs.append(temp(cl[:, f].contiguous(), offset_list=outs[0][2]))
+        return s_loc, maps, outs
+    s_loc, maps, outs = run(clips, "bf16")
+    for c in (0, 5, 7):
+        s1, m1, o1 = run(clips[c:c + 1], "bf16")
+        assert torch.equal(s1[0], s_loc[c]) and torch.equal(m1[0][0], maps[0][c])
+        for f in range(4):
+            assert torch.equal(o1[f][0][0], outs[f][0][c]), (c, f)
+            assert torch.equal(o1[f][1], outs[f][1].view(8, 6375, 21)[c])
+        assert torch.equal(o1[0][2][1][0], outs[0][2][1][c])
+    # fp32, one clip, against the oracle
+    c = 3
+    s1, m1, o1 = run(clips[c:c + 1], "fp32")
+    xk = clips[c, 0:1].cpu().numpy()
+    r_loc, r_conf, r_maps = net_ref.ssd4scale_vgg_forward(sd_s, xk, 21, "test", True, False, ret_loc=True)
+    np.testing.assert_allclose(s1.cpu().numpy(), r_loc.numpy(), atol=1e-3, rtol=0)
+    rt_loc, rt_conf, r_offs = net_ref.ssd4scale_vgg_forward(sd_t, xk, 21, "test", True, True, ref_loc=r_maps, ret_off=True)
+    np.testing.assert_allclose(o1[0][0].cpu().numpy(), rt_loc.numpy(), atol=2e-3, rtol=0)
+    np.testing.assert_allclose(o1[0][1].cpu().numpy(), rt_conf.numpy(), atol=1e-3, rtol=0)
+    x1 = clips[c, 1:2].cpu().numpy()
+    r1 = net_ref.ssd4scale_vgg_forward(sd_t, x1, 21, "test", True, True, offset_list=r_offs)
+    np.testing.assert_allclose(o1[1][0].cpu().numpy(), r1[0].numpy(), atol=2e-3, rtol=0)
+    # refinedet_vgg, batch 8
+    rd, _ = _build("refinedet_vgg", (320, 21, True, 1024, True, True))
+    rd.bfloat16()
+    _rows_equal_single_runs(rd, clips[:, 0].contiguous(), (0, 4, 7))
 
 
 def test_state_dict_roundtrip_and_missing_num_batches_tracked():
@@ -381,3 +505,43 @@ def test_multi_scale_flip_tester():
     assert sorted(voted) == sorted(again) and all(np.array_equal(voted[j], again[j]) for j in voted)
     for j, boxes in voted.items():
         assert boxes.shape[1] == 5 and (boxes[:, 4] > 0).all()
+
+
+@pytest.mark.parametrize("ssd_dim,mh", [(320, False), (512, True)])
+def test_multi_scale_tester_runs_the_references_full_scale_lists(ssd_dim, mh):
+    """multi_eval.py:21-24: a 320-net is tested at [192, 320, 384, 448, 512, 576, 704] and a 512-net at [320, 512, 640,
+    1216] (P up to 30855 / 92055: beyond what an LDS-resident Detect could hold).  Every view yields a full result;
+    at the largest scale the device pipeline equals the oracle's Detect on the same net outputs, bit for bit."""
+    from tdrn_amd.data import base_transform, multi_cfg, multi_cfg_512, MEANS
+    from tdrn_amd.eval import MultiScaleTester
+    from tdrn_amd.eval.tta import MULTI_SCALE
+    net, _ = _build("dualrefinedet_vggbn", (ssd_dim, 21, 1024, 1, True, mh))
+    cfgs = multi_cfg if ssd_dim == 320 else multi_cfg_512
+    scales = MULTI_SCALE[str(ssd_dim)]
+    assert scales == ([192, 320, 384, 448, 512, 576, 704] if ssd_dim == 320 else [320, 512, 640, 1216])
+    pri = {s: PriorBox(cfgs[str(s)]).forward().to(DEV) for s in scales}
+    rng = np.random.Generator(np.random.PCG64(19))
+    frame = torch.from_numpy(rng.integers(0, 256, (360, 480, 3), dtype=np.uint8)).to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45)
+    tester = MultiScaleTester(net, det, pri, ssd_dim=ssd_dim, mean=MEANS)
+    voted, multi = tester.detect(frame)
+    assert sorted(multi) == sorted("%d_%d_%d" % (ssd_dim, s, f) for s in scales for f in (0, 1))
+    assert all(v.shape == (1, 21, 200, 5) and np.isfinite(v).all() for v in multi.values())
+    assert len(voted) > 0
+    top = scales[-1]
+    P = pri[top].shape[0]
+    assert P == 3 * sum((top // st) ** 2 for st in (8, 16, 32, 64)) and P > 16384
+    x = base_transform(frame, top, MEANS, True)
+    arm, _, odm, conf = net(x)
+    got = det.forward(odm, conf, pri[top], arm_loc_data=arm).cpu().numpy()
+    assert np.array_equal(got, multi["%d_%d_0" % (ssd_dim, top)])
+    # the oracle's full cpu_nms over ~P candidates x 20 classes is slow at P = 92055: check five classes there
+    classes = range(1, 21) if P < 40000 else (1, 5, 9, 14, 20)
+    cf = conf.cpu().numpy().copy()
+    keep_cols = np.zeros(21, bool)
+    keep_cols[list(classes)] = True
+    cf[:, ~keep_cols] = 0.0                                     # (below conf_thresh: those classes produce no candidates)
+    ref = orc.detect(odm.cpu().numpy(), cf, pri[top].cpu().numpy(), arm.cpu().numpy(), (320,) * 4)
+    for c in classes:
+        assert np.array_equal(got[0, c, :, 0], ref[0, c, :, 0]), c
+        np.testing.assert_allclose(got[0, c], ref[0, c], rtol=3e-6, atol=1e-6)
