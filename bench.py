@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the box / score error block (one oracle forward on the host)")
     ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
+    ap.add_argument("--graph", type=int, default=1, help="1: the step (forward + Detect) is one captured hipGraph replay; 0: eager launches")
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=96)      # ~16 s of CPU work on the GPU box host
     args = ap.parse_args()
@@ -195,6 +196,17 @@ def main():
             streams[0].wait_stream(streams[i])
         return outs
 
+    if args.graph and NS == 1:
+        from tdrn_amd.engine import GraphedCall
+
+        def one_step(xin):
+            r = eng.forward(xin)
+            return r["conf"] if args.no_detect else det.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
+        graphed = GraphedCall(one_step, x)
+        x = graphed.inputs[0]                      # the batch lives in the captured input buffer: no per-step copy
+
+        def step():
+            return graphed(x)
     for _ in range(args.warmup):
         step()
     tdist.barrier()
@@ -243,7 +255,8 @@ def main():
             "config": {"workload": "dualrefinedet_vggbn %dx%d multihead, %s, batch %d per GPU, forward%s, synthetic "
                                    "VOC-shaped frames + synthetic weights" %
                                    (args.size, args.size, args.dtype, B, "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
-                       "global_batch": world * B, "parallelism": "frame-sharded x%d, no per-frame collective" % world},
+                       "global_batch": world * B, "parallelism": "frame-sharded x%d, no per-frame collective" % world,
+                       "launch": "hipGraph replay" if (args.graph and NS == 1) else "eager"},
             "fps_per_gpu": round(fps / world, 2),
             "forward_only_ms_per_step": round(fwd_ms, 4),
             "forward_tflops": round(GFLOP_PER_FRAME.get(args.size, 0) * B / fwd_ms, 2),

@@ -1,3 +1,6 @@
 mkdir -p gpurun_out/r2
-timeout 1500 python -m pytest tests/test_gpu_net.py tests/test_gpu_dist.py -x -q -m gpu -s > gpurun_out/r2/t_net3.log 2>&1
-python bench.py > gpurun_out/r2/bench_a.json 2> gpurun_out/r2/bench_a.err
+timeout 600 python -m pytest tests/test_gpu_net.py -x -q -m gpu -k hipgraph > gpurun_out/r2/t_graph.log 2>&1
+for rep in 1 2; do
+python bench.py --no-cpu-baseline --no-parity --graph 1 > gpurun_out/r2/bench_g1_$rep.json 2> gpurun_out/r2/bench_g1.err
+python bench.py --no-cpu-baseline --no-parity --graph 0 > gpurun_out/r2/bench_g0_$rep.json 2> gpurun_out/r2/bench_g0.err
+done

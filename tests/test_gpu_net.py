@@ -545,3 +545,27 @@ def test_multi_scale_tester_runs_the_references_full_scale_lists(ssd_dim, mh):
     for c in classes:
         assert np.array_equal(got[0, c, :, 0], ref[0, c, :, 0]), c
         np.testing.assert_allclose(got[0, c], ref[0, c], rtol=3e-6, atol=1e-6)
+
+
+def test_hipgraph_replay_equals_eager():
+    """The whole step (net forward on its four stream lanes + Detect) captured as ONE hipGraph (engine.GraphedCall):
+    replays are bit-identical to eager launches, also after the input buffer is refilled."""
+    from tdrn_amd.engine import GraphedCall
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    net.bfloat16()
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = Detect(21, 0, 200, 0.01, 0.45)
+
+    def step(x):
+        arm, _, odm, conf = net(x)
+        return arm, odm, conf, det.forward(odm, conf, pri, arm_loc_data=arm, scale=[500.0, 375.0, 500.0, 375.0])
+    xa = torch.from_numpy(synth.synth_frames(4, 320, seed=61)).to(DEV)
+    xb = torch.from_numpy(synth.synth_frames(4, 320, seed=62)).to(DEV)
+    ea = [t.clone() for t in step(xa)]
+    eb = [t.clone() for t in step(xb)]
+    g = GraphedCall(step, xa)
+    for x, e in ((xa, ea), (xb, eb), (xa, ea)):
+        out = g(x)
+        torch.cuda.synchronize()
+        for got, want in zip(out, e):
+            assert torch.equal(got, want)
