@@ -113,9 +113,14 @@ constexpr int kSlotsPerLoader = (kPatchSlots + 3) / 4;
 
 }  // namespace
 
-template <typename DT, int BN, bool FLAT>
+// TW = 32 / 16: 2-D tiles of (256/TW) x TW pixels of one image; TW = 0: flat tiles.  Compile-time: with a runtime
+// tile width every per-element step of the pooled epilogue carried a branch and the index math its shifts as variables.
+template <typename DT, int BN, int TW>
 __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 {
+    constexpr bool FLAT = TW == 0;
+    constexpr int LGTW = TW == 32 ? 5 : 4;              // (2-D tiles only)
+    constexpr int TH = TW ? 256 / TW : 0;
     constexpr int ES = elem_traits<DT>::bytes;
     constexpr int P16 = elem_traits<DT>::per16;
     constexpr int CK = 128 / ES;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     const int n_it = avail > slot ? (avail - slot + istride - 1) / istride : 0;
     const int item0 = xcd * per_xcd + slot;
     const int n_steps = n_it * nchunks * 9;
-    const int RS = p.tw ? p.tw + 2 : p.W;              // patch row stride of one image row
+    const int RS = TW ? TW + 2 : p.W;                  // patch row stride of one image row
 
     if (wave >= 8) {
         // =========================== LOADER ===========================
@@ -160,14 +165,13 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         int pyx[kSlotsPerLoader];                       // (py << 16 | px) of my patch row, -1 = beyond the patch
         int plc[kSlotsPerLoader];                       // swizzled 16-B chunk offset inside the 128-B row
         {
-            const int th = p.tw ? 256 / p.tw : 0;
 #pragma unroll
             for (int j = 0; j < kSlotsPerLoader; ++j) {
                 const int pr = (lw + 4 * j) * 8 + lrow;
                 plc[j] = (pc ^ ((pr >> 1) & 7)) << 4;
-                if (p.tw) {
+                if (TW) {
                     const int py = pr / RS, px = pr - py * RS;
-                    pyx[j] = py < th + 2 ? ((py << 16) | px) : -1;
+                    pyx[j] = py < TH + 2 ? ((py << 16) | px) : -1;
                 } else {
                     pyx[j] = pr < 256 + 2 * p.W + 2 ? pr : -1;
                 }
@@ -179,11 +183,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             if (mt == table_mt) return;
             table_mt = mt;
             const long long rowbytes = (long long)p.Cin * ES;
-            if (p.tw) {
-                const int th = 256 / p.tw;
+            if (TW) {
                 const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
                 const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-                const int y0 = ty * th - 1, x0 = tx * p.tw - 1;
+                const int y0 = ty * TH - 1, x0 = tx * TW - 1;
 #pragma unroll
                 for (int j = 0; j < kSlotsPerLoader; ++j) {
                     const int y = y0 + (pyx[j] >> 16), x = x0 + (pyx[j] & 0xffff);
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int i = cw * 64 + pt * 32 + r32;          // tile-local pixel
-        base_i[pt] = p.tw ? (i >> p.lgtw) * RS + (i & (p.tw - 1)) : i;
+        base_i[pt] = TW ? (i >> LGTW) * RS + (i & (TW - 1)) : i;
     }
     const int wsw = (r32 >> 1) & 7;                     // swizzle of my weight rows (row = 32*ci + r32)
     constexpr int CPR = BNH * ES / 16;                  // 16-B chunks per pixel (my cout half)
@@ -334,17 +337,19 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     // ---- per-item state ---------------------------------------------------------------------------
     int cur_mt = -1, n0 = 0;
     long long tile_pix0 = 0;                            // 2-D: global pixel of the tile's (0,0); flat: mt*256
+    int tile_row0 = 0, tile_x0 = 0;                     // 2-D: b*H + y and x of the tile's (0,0)
     auto setup_item = [&](int it) {
         const int item = item0 + it * istride;
         const int mt = item / p.n_tiles;
         n0 = (item - mt * p.n_tiles) * BN;
         if (mt == cur_mt) return;
         cur_mt = mt;
-        if (p.tw) {
-            const int th = 256 / p.tw;
+        if (TW) {
             const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
             const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-            tile_pix0 = ((long long)b * p.H + ty * th) * p.W + tx * p.tw;
+            tile_row0 = b * p.H + ty * TH;
+            tile_x0 = tx * TW;
+            tile_pix0 = (long long)tile_row0 * p.W + tile_x0;
             return;
         }
         tile_pix0 = (long long)mt * 256;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     auto epilogue = [&]() {
         const int my_c = n0 + chalf * BNH + my_ch * P16;
         auto pixel_of = [&](int i) -> long long {       // global pixel of tile-local pixel i (or -1)
-            if (p.tw) return tile_pix0 + (long long)(i >> p.lgtw) * p.W + (i & (p.tw - 1));
+            if (TW) return tile_pix0 + (long long)(i >> LGTW) * p.W + (i & (TW - 1));
             const long long m = tile_pix0 + i;
             return m < p.M ? m : -1;
         };
@@ -428,18 +433,18 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             // applied at staging): the partner row is my other pixel tile (tw = 32) or lane^16
             // (tw = 16); the partner column is lane^1.  Even-x lanes of the top row hold the result.
             const int PW = p.W >> 1;
-            const int npool = p.tw == 32 ? 16 : 8;      // pooled pixels per pixel tile
-            const bool holder = (r32 & 1) == 0 && (p.tw == 32 || r32 < 16);
+            constexpr int npool = TW == 32 ? 16 : 8;    // pooled pixels per pixel tile
+            const bool holder = (r32 & 1) == 0 && (TW == 32 || r32 < 16);
             const int prow_l = r32 >> 1;
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
-                if (p.tw == 32 && pt == 1) break;
+                if (TW == 32 && pt == 1) break;
 #pragma unroll
                 for (int ci = 0; ci < WC; ++ci)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float v = acc[ci][pt][e];
-                        if (p.tw == 32) v = fmaxf(v, acc[ci][1][e]);
+                        if (TW == 32) v = fmaxf(v, acc[ci][1][e]);
                         else v = fmaxf(v, __shfl_xor(v, 16, 64));
                         v = fmaxf(v, __shfl_xor(v, 1, 64));
                         acc[ci][pt][e] = v;
@@ -461,11 +466,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                         if (row < rows_here && my_c < p.Cout) {
                             const int pl = rd * SROWS + row;            // pooled pixel within this pixel tile
                             const int i0 = cw * 64 + pt * 32 + 2 * pl;  // top-left pixel of the 2x2 window
-                            const long long g0 = tile_pix0 + (long long)(i0 >> p.lgtw) * p.W + (i0 & (p.tw - 1));
-                            // g0 = (b*H + y)*W + x with y, x even  ->  pooled index ((b*H + y)/2)*PW + x/2
-                            const long long bh = g0 / p.W;
-                            const int x = (int)(g0 - bh * p.W);
-                            const long long gpool = (bh >> 1) * PW + (x >> 1);
+                            // window (b*H + y, x) with y, x even (H is even)  ->  pooled index ((b*H + y)/2)*PW + x/2
+                            const long long gpool = (long long)((tile_row0 + (i0 >> LGTW)) >> 1) * PW + ((tile_x0 + (i0 & (TW - 1))) >> 1);
                             *(u32x4 *)(p.out_pool + ((size_t)gpool * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
                         }
                     }
@@ -607,11 +609,11 @@ int patch_conv_supported(const ConvArgs &a)
 
 template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p, hipStream_t s)
 {
-    const bool flat = p.tw == 0;
     // a multiple of 8 workgroups (the item split is per XCD); surplus workgroups find no item and exit
     const int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
-    if (flat) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, true>), dim3(grid), dim3(768), 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, false>), dim3(grid), dim3(768), 0, s, p);
+    if (p.tw == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 0>), dim3(grid), dim3(768), 0, s, p);
+    else if (p.tw == 32) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 32>), dim3(grid), dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 16>), dim3(grid), dim3(768), 0, s, p);
     return hip_status(hipGetLastError());
 }
 
