@@ -168,8 +168,10 @@ def softmax_rows(x):
 def base_transform_u8(image, size, mean_bgr, to_rgb=False):
     """data/__init__.py:7-12 + data/voc0712.py:467-468 for uint8 BGR frames (B,H,W,3) -> (B,3,S,S) fp32.
     cv2.resize(INTER_LINEAR, 8-bit) restated from OpenCV imgproc/resize.cpp (11-bit fixed-point coefficients;
-    vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  PARITY UNPINNED: cv2 is not installed
-    in the build image, so this restatement could not be checked against cv2 itself."""
+    vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  PARITY UNPINNED BY THE REFERENCE: cv2 is not
+    installed in the build image, so no output of cv2 itself exists to compare with.  What pins it instead are
+    known-answer cases worked by hand from OpenCV's algorithm (tests/test_oracle_pin.py: identity, exact 2:1 = rounded
+    block mean, exact 1:2 = (512, 1536)/2048 weights with border clamp, a 3x3 -> 2x2 case through both fixed-point passes)."""
     img = np.asarray(image, np.uint8)
     if img.ndim == 3:
         img = img[None]

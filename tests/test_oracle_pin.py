@@ -236,3 +236,72 @@ def test_other_model_restatements_match_reference(golden_dir):
         np.testing.assert_allclose(tloc.numpy()[:, ::sub], g[tag + "_tloc"], **tol)
         np.testing.assert_allclose(tconf.numpy().reshape(1, -1, 21)[:, ::sub], g[tag + "_tconf"], **tol)
         np.testing.assert_allclose(offs[3].numpy(), g[tag + "_off3"], **tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocess oracle (cv2 is absent from the image: no fixture from the reference is possible, so the restatement of
+# cv2.resize(INTER_LINEAR, 8-bit) is pinned by known-answer cases whose answers do not come from its own code)
+# ---------------------------------------------------------------------------------------------
+def test_preprocess_identity_is_pixel_minus_mean():
+    rng = np.random.Generator(np.random.PCG64(3))
+    img = rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    mean = (104, 117, 123)
+    out = orc.base_transform_u8(img, 64, mean, to_rgb=False)
+    assert np.array_equal(out, (img.astype(np.float32) - np.asarray(mean, np.float32)).transpose(0, 3, 1, 2))
+    rgb = orc.base_transform_u8(img, 64, mean, to_rgb=True)       # voc0712.py:467-468: channels reversed AFTER the mean
+    assert np.array_equal(rgb, out[:, ::-1])
+
+
+def test_preprocess_exact_two_to_one_is_the_rounded_block_mean():
+    """dst = src/2: every sample sits exactly between two source pixels (coefficients 1024/1024 of 2048), so the
+    result is the 2x2 block mean; cv2's fixed-point pipeline rounds it half up: (a+b+c+d+2) >> 2."""
+    rng = np.random.Generator(np.random.PCG64(4))
+    img = rng.integers(0, 256, (1, 32, 48, 3), dtype=np.uint8)
+    out = orc.base_transform_u8(img, 16, (0, 0, 0))               # non-square source on purpose: 32x48 -> 16x16 is 2:1 / 3:1
+    blocks = img[0, :, :, :].astype(np.int64).reshape(16, 2, 48, 3).sum(1)          # vertical pairs
+    got_rows = out[0].transpose(1, 2, 0)                                            # (16,16,3)
+    # horizontal 3:1: sample x = 3*dx + 1 exactly (fraction 0) -> column 3dx+1 alone; vertical 2:1 -> mean of the pair
+    expect = (2 * blocks[:, 1::3, :] + 2) >> 2                                      # (a+a+c+c+2)>>2 with identical horizontal pair
+    assert np.array_equal(got_rows, expect.astype(np.float32))
+    sq = rng.integers(0, 256, (1, 32, 32, 3), dtype=np.uint8)
+    out = orc.base_transform_u8(sq, 16, (0, 0, 0))[0].transpose(1, 2, 0)
+    s = sq[0].astype(np.int64)
+    expect = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(out, expect.astype(np.float32))
+
+
+def test_preprocess_exact_one_to_two_quarter_weights_and_border_clamp():
+    """dst = 2*src: samples fall at k -/+ 0.25 -> weights (0.25, 0.75) = (512, 1536)/2048; the outermost samples
+    (source coordinate -0.25 and n-0.75) clamp to the border pixel (cv2: sx < 0 -> sx = 0, fx = 0; sx >= n-1 -> fx = 0).
+    On a horizontal ramp with constant rows the vertical pass is the identity, so the answer is a 1-D formula."""
+    ramp = (np.arange(8) * 32).astype(np.uint8)                 # 0, 32, ..., 224
+    img = np.broadcast_to(ramp[None, None, :, None], (1, 8, 8, 3)).copy()
+    out = orc.base_transform_u8(img, 16, (0, 0, 0))[0, 0]        # (16,16), all rows equal
+    assert (out == out[0]).all()
+    p = ramp.astype(np.int64)
+    exp = np.empty(16, np.int64)
+    exp[0] = p[0]
+    exp[15] = p[7]
+    for k in range(1, 8):
+        exp[2 * k] = (512 * p[k - 1] + 1536 * p[k] + 1024) >> 11          # k - 0.25
+    for k in range(0, 7):
+        exp[2 * k + 1] = (1536 * p[k] + 512 * p[k + 1] + 1024) >> 11      # k + 0.25
+    assert np.array_equal(out[0], exp.astype(np.float32))
+
+
+def test_preprocess_hand_computed_3x3_to_2x2():
+    """3x3 -> 2x2: source coordinates 0.25 and 1.75 in both axes -> coefficient pairs (1536, 512) and (512, 1536).
+    Worked by hand with OpenCV's two passes (horizontal sums kept at 11 fractional bits, vertical pass
+    (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2):
+        src = [[ 10,  20,  30],      H-pass rows: [1536*10+512*20, 512*20+1536*30] = [25600, 56320]
+               [ 40,  50,  60],                   [1536*40+512*50, 512*50+1536*60] = [87040, 117760]
+               [ 70,  80,  90]]                   [1536*70+512*80, 512*80+1536*90] = [148480, 179200]
+        dst[0][0] = ((1536*(25600>>4))>>16) + ((512*(87040>>4))>>16) + 2 >> 2 = (37 + 42 + 2) >> 2 = 20
+        dst[0][1] = ((1536*3520)>>16) + ((512*7360)>>16) + 2 >> 2 = (82 + 57 + 2) >> 2 = 35
+        dst[1][0] = ((512*5440)>>16) + ((1536*9280)>>16) + 2 >> 2 = (42 + 217 + 2) >> 2 = 65
+        dst[1][1] = ((512*7360)>>16) + ((1536*11200)>>16) + 2 >> 2 = (57 + 262 + 2) >> 2 = 80"""
+    src = np.asarray([[10, 20, 30], [40, 50, 60], [70, 80, 90]], np.uint8)
+    img = np.repeat(src[None, :, :, None], 3, axis=3)
+    out = orc.base_transform_u8(img, 2, (0, 0, 0))[0]
+    assert np.array_equal(out[0], np.asarray([[20, 35], [65, 80]], np.float32))
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], out[2])
