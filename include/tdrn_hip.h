@@ -61,6 +61,7 @@ typedef enum { TDRN_F32 = 0, TDRN_BF16 = 1, TDRN_F16 = 2 } tdrn_dtype;
  *   output (N, Cout, Ho, Wo) fp32, device, fully overwritten
  *   `columns` / `ones` of the reference have no counterpart: the sampled columns never leave
  *   LDS.  `compute` selects the MFMA input type (TDRN_F32 reproduces the reference's fp32).
+ *   Kernel size, stride, padding and dilation are per axis, as in the reference (any kH x kW).
  *   Shape errors mirror shape_check (deform_conv_cuda.c:7-96, :137) -> TDRN_E_SHAPE.
  * ====================================================================================== */
 TDRN_API size_t tdrn_deform_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kH,
@@ -224,8 +225,10 @@ TDRN_API int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *work
 
 /* Per-kernel accounting of the LAST forward for bench.py's roofline line: algorithmic FLOPs
  * and bytes per kernel family, and (when profiling is enabled) hipEvent-measured time.
- * tdrn_net_profile(net, 1) makes the next forwards record an event pair around every launch
- * on `stream` (adds launch gaps: use only in a dedicated profiling pass). */
+ * tdrn_net_profile(net, 1) makes the next forwards record an event pair around every launch and run
+ * everything on `stream` (no overlap: the kernel's own duration); tdrn_net_profile(net, 2) records the
+ * same pairs on the production schedule (side lanes on: the duration a launch has in the real step).
+ * Both add launch gaps: use only in a dedicated profiling pass. */
 typedef struct {
     char name[48];
     int launches;

@@ -28,8 +28,7 @@ int deform_plan(int N, int Cin, int H, int W, int Cout, int kH, int kW, int dH, 
     p.Wo = (W + 2 * padW - (dilW * (kW - 1) + 1)) / dW + 1;
     if (p.Ho < 1 || p.Wo < 1) return TDRN_E_SHAPE;
     if (H < kH || W < kW) return TDRN_E_SHAPE;
-    // the fused kernel is square-parameterised (every caller in the reference is: networks.py:699-733)
-    if (kH != kW || dH != dW || padH != padW || dilH != dilW) return TDRN_E_UNSUPPORTED;
+    if (padH < 0 || padW < 0) return TDRN_E_SHAPE;
     const int es = dtype_bytes(dtype);
     p.taps = kH * kW;
     p.ck = 128 / es;
@@ -100,7 +99,7 @@ int tdrn_deform_conv_forward(const float *input, const float *weight, const floa
         DeformArgs a;
         a.in = ws + p.o_in; a.zero_page = ws + p.o_zero; a.n_branches = 1;
         a.br[0] = DeformBranch{(const float *)(ws + p.o_off), offC, ws + p.o_w + (size_t)c0 * p.taps * p.Cin_pad * es,
-                               kH, kW, padH, dH, dilationH, G};
+                               kH, kW, padH, dH, dilationH, G, padW, dW, dilationW};
         a.B = N; a.H = H; a.W = W; a.Cin = p.Cin_pad; a.Ho = p.Ho; a.Wo = p.Wo; a.Cout = cn; a.Npad = deform_n_pad(cn);
         a.out0 = out_nhwc + c0; a.o0_bs = (long long)p.Ho * p.Wo * Cout; a.o0_ps = Cout; a.split = cn;
         a.dtype = compute;

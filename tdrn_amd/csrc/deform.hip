@@ -18,7 +18,8 @@ namespace tdrn {
 struct DeformBranchP {
     const float *off;
     const char *w;
-    int off_stride, kh, kw, pad, stride, dil, G, pad_;
+    int off_stride, kh, kw, G;
+    int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;      // per axis, like deform_conv_cuda.c:98-103
 };
 struct DeformParams {
     const char *in, *zero;
@@ -146,12 +147,12 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
             int o1 = ibase[i], o2 = ibase[i], o3 = ibase[i], o4 = ibase[i];
             if (mrow[i] >= 0) {
                 const float offset_h = offh[i], offset_w = offw[i];
-                const int h_in = ho_[i] * B.stride - B.pad, w_in = wo_[i] * B.stride - B.pad;
-                const float h_im = (float)(h_in + ti * B.dil) + offset_h;
-                const float w_im = (float)(w_in + tj * B.dil) + offset_w;
+                const int h_in = ho_[i] * B.stride_h - B.pad_h, w_in = wo_[i] * B.stride_w - B.pad_w;
+                const float h_im = (float)(h_in + ti * B.dil_h) + offset_h;
+                const float w_im = (float)(w_in + tj * B.dil_w) + offset_w;
                 if (h_im >= 0.f && w_im >= 0.f && h_im < (float)p.H && w_im < (float)p.W) {
-                    float h = (float)(ti * B.dil) + offset_h;     // map_h, relative to h_in
-                    float w = (float)(tj * B.dil) + offset_w;
+                    float h = (float)(ti * B.dil_h) + offset_h;     // map_h, relative to h_in
+                    float w = (float)(tj * B.dil_w) + offset_w;
                     const int height = p.H - h_in, width = p.W - w_in;
                     int h_low = (int)floorf(h), w_low = (int)floorf(w), h_high, w_high;
                     if (h_low >= height - 1) { h_high = h_low = height - 1; h = (float)h_low; } else { h_high = h_low + 1; }
@@ -326,7 +327,10 @@ static int fill_params(const DeformArgs &a, DeformParams &p)
     for (int i = 0; i < a.n_branches; ++i) {
         const DeformBranch &b = a.br[i];
         if (!b.off || !b.w || b.G < 1 || a.Cin % b.G || (a.Cin / b.G) % ck) return TDRN_E_UNSUPPORTED;
-        p.br[i] = DeformBranchP{b.off, (const char *)b.w, b.off_stride, b.kh, b.kw, b.pad, b.stride, b.dil, b.G, 0};
+        if (b.kh < 1 || b.kw < 1 || b.stride < 1 || b.dil < 1) return TDRN_E_SHAPE;
+        p.br[i] = DeformBranchP{b.off, (const char *)b.w, b.off_stride, b.kh, b.kw, b.G,
+                                b.pad, b.pad_w < 0 ? b.pad : b.pad_w, b.stride, b.stride_w < 1 ? b.stride : b.stride_w,
+                                b.dil, b.dil_w < 1 ? b.dil : b.dil_w};
     }
     if (a.n_branches == 1) p.br[1] = p.br[0];
     p.M = a.B * a.Ho * a.Wo;

@@ -97,7 +97,8 @@ struct DeformBranch {
     const float *off = nullptr;
     int off_stride = 0;
     const void *w = nullptr;
-    int kh = 3, kw = 3, pad = 1, stride = 1, dil = 1, G = 1;
+    int kh = 3, kw = 3, pad = 1, stride = 1, dil = 1, G = 1;      // pad / stride / dil: the H axis
+    int pad_w = -1, stride_w = -1, dil_w = -1;                     // W axis; < 0 (< 1): same as the H axis
 };
 struct DeformArgs {
     const void *in = nullptr, *zero_page = nullptr;

@@ -79,7 +79,7 @@ struct tdrn_net {
     size_t ws_per_sample = 0, blob_bytes = kZeroPageBytes;
     int P = 0, fm[4] = {0, 0, 0, 0}, scale_off[5] = {0, 0, 0, 0, 0};
     bool weights_ready = false;
-    bool profile = false;
+    int profile = 0;                   // 0 off; 1 = events around every launch, single stream; 2 = the same with the side lanes on
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_stat;
     std::vector<int> ev_op;
@@ -860,8 +860,9 @@ struct tdrn_net {
         }
         ev_stat.clear();
         ev_op.clear();
-        // profiling runs single-stream so that per-kernel durations are not polluted by overlap
-        const bool lanes = use_lanes && !profile;
+        // profile 1 runs single-stream (per-kernel durations without overlap); profile 2 keeps the production lanes, so a
+        // launch's duration includes what the concurrent side-lane kernels take from it
+        const bool lanes = use_lanes && profile != 1;
         bool lane_used[kLanes] = {true, false, false, false};
         if (lanes) {
             TDRN_TRY(init_lanes());
@@ -1206,7 +1207,7 @@ int tdrn_net_read_tensor(const tdrn_net *net, const void *workspace, int batch, 
 int tdrn_net_profile(tdrn_net *net, int enable)
 {
     if (!net) return TDRN_E_ARG;
-    net->profile = enable != 0;
+    net->profile = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return TDRN_OK;
 }
 

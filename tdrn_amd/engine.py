@@ -166,8 +166,9 @@ class NetEngine(object):
         return out
 
     # ---- accounting for bench.py -------------------------------------------------------------
-    def set_profile(self, on):
-        check(self.lib.tdrn_net_profile(self.handle, int(bool(on))))
+    def set_profile(self, mode):
+        """0 / False: off; 1 / True: per-launch events, single stream; 2: per-launch events on the production lanes."""
+        check(self.lib.tdrn_net_profile(self.handle, int(mode)))
 
     def kernel_stats(self):
         arr = (KernelStat * 16)()

@@ -45,16 +45,22 @@ DEFORM_CASES = [
     (1, 16, 9, 9, 8, 3, 1, 2, 2, 1, 1.0),       # dilation 2
     (1, 8, 6, 6, 140, 1, 1, 0, 1, 1, 0.7),      # Cout > 128 (two channel chunks), 1x1
     (3, 256, 5, 5, 75, 3, 1, 1, 1, 1, 3.0),     # smallest pyramid level, big offsets (all borders)
+    # non-square kernel / stride / padding / dilation (shape_check, deform_conv_cuda.c:7-96, takes them per axis)
+    (2, 16, 11, 13, 9, (3, 5), 1, (1, 2), 1, 1, 1.0),
+    (1, 32, 14, 9, 12, (1, 3), (2, 1), (0, 1), 1, 2, 1.5),
+    (1, 8, 12, 12, 6, (3, 2), (1, 2), (2, 0), (2, 1), 1, 1.0),
 ]
+_pr = lambda v: (v, v) if isinstance(v, int) else tuple(v)
 
 
 @pytest.mark.parametrize("case", DEFORM_CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_deform_conv_fp32_matches_oracle(case):
     N, Cin, H, W, Cout, k, st, pad, dil, G, osc = case
-    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // st + 1
-    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // st + 1
-    x, w = _rand((N, Cin, H, W), 1), _rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5)
-    off = _rand((N, G * 2 * k * k, Ho, Wo), 3, osc)
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = _pr(k), _pr(st), _pr(pad), _pr(dil)
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    x, w = _rand((N, Cin, H, W), 1), _rand((Cout, Cin, kh, kw), 2, (Cin * kh * kw) ** -0.5)
+    off = _rand((N, G * 2 * kh * kw, Ho, Wo), 3, osc)
     ref = orc.deform_conv_forward(x, off, w, st, pad, dil, G)
     got = conv_offset2d(_cu(x), _cu(off), _cu(w), st, pad, dil, G).cpu().numpy()
     assert got.shape == ref.shape
