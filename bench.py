@@ -233,15 +233,17 @@ def main():
         eng.forward(x)
         torch.cuda.synchronize()
         st = eng.kernel_stats()
-        ops = eng.op_stats() if (args.per_op and mode == 1) else None
+        ops = eng.op_stats() if args.per_op else None
         eng.set_profile(0)
         return st, ops
     stats, ops = profiled(1)                                 # every launch alone on one stream
-    stats_prod, _ = profiled(2)                              # the production schedule (side lanes on)
+    stats_prod, ops_prod = profiled(2)                       # the production schedule (side lanes on)
     if ops and rank == 0:
+        prod = {o["name"]: o["ms"] for o in ops_prod}
+        print("%-44s %11s %11s %8s %9s %8s" % ("launch", "alone us", "in step us", "GFLOP", "TFLOP/s", "GB"), file=sys.stderr)
         for o in ops:
             tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
-            print("%-44s %8.1f us %8.1f GF %7.1f TF/s %7.2f GB" % (o["name"], o["ms"] * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
+            print("%-44s %11.1f %11.1f %8.1f %9.1f %8.2f" % (o["name"], o["ms"] * 1e3, prod.get(o["name"], 0.0) * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
     conv = max(stats_prod, key=lambda s: s["ms"])            # the dominant kernel family of the step
     solo = next(s for s in stats if s["name"] == conv["name"])
     peak = PEAK_TFLOPS[args.dtype]

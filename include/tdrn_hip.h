@@ -92,6 +92,16 @@ TDRN_API size_t tdrn_nms_workspace_bytes(int n);
 TDRN_API int tdrn_nms(const float *dets, int n, double thresh, int strict_gt, int32_t *keep_out,
                       int32_t *num_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The torch NMS that DetectOTA uses -- replaces
+ *     nms(boxes, scores, overlap=0.5, top_k=200) -> (keep, count)       layers/box_utils.py:229-293
+ *   dets (n,5) device fp32 rows [x1,y1,x2,y2,score], normalised coordinates, NO "+1": area = (x2-x1)*(y2-y1),
+ *   IoU = inter / ((area_j - inter) + area_i) in fp32; a candidate survives iff IoU <= overlap (fp32).  Only boxes
+ *   with score > min_score are candidates (the caller's c_mask, detection_ota.py:67-68) and only the top_k best
+ *   of them enter (box_utils.py:251; 0 = all).  keep_out (n) <- kept indices into dets, descending score. */
+TDRN_API int tdrn_nms_topk(const float *dets, int n, float overlap, float min_score, int top_k,
+                           int32_t *keep_out, int32_t *num_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* COMPAT twin of   void _nms(int* keep_out, int* num_out, const float* boxes_host,
  *     int boxes_num, int boxes_dim, float nms_overlap_thresh, int device_id)
  *                                                          utils/nms/gpu_nms.hpp:1-2

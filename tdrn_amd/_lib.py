@@ -49,6 +49,8 @@ _SIGS = {
     "tdrn_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
     "tdrn_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tdrn_nms_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "tdrn_gpu_nms_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
     "tdrn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "tdrn_center_size": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -116,6 +116,14 @@ int tdrn_nms(const float *dets, int n, double thresh, int strict_gt, int32_t *ke
     return launch_nms(dets, n, thresh, strict_gt, 0, keep_out, num_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int tdrn_nms_topk(const float *dets, int n, float overlap, float min_score, int top_k, int32_t *keep_out, int32_t *num_out,
+                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (top_k < 0) return TDRN_E_ARG;
+    return launch_nms(dets, n, (double)overlap, 0, 0, keep_out, num_out, workspace, workspace_bytes, (hipStream_t)stream, 1, min_score,
+                      top_k);
+}
+
 int tdrn_gpu_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
                       float nms_overlap_thresh, int device_id)
 {

@@ -166,8 +166,9 @@ struct KeepList {
     __device__ __forceinline__ Box get(int i) const { const f32x4 v = c[i]; return Box{v[0], v[1], v[2], v[3], area[i]}; }
     __device__ __forceinline__ void set(int i, const Box &b) const { c[i] = f32x4{b.x1, b.y1, b.x2, b.y2}; area[i] = b.area; }
 };
-__device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2)
-{   // cpu_nms.pyx:24  (x2 - x1 + 1) * (y2 - y1 + 1)
+__device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2, int plain = 0)
+{   // cpu_nms.pyx:24  (x2 - x1 + 1) * (y2 - y1 + 1);  plain (layers/box_utils.py:247): (x2 - x1) * (y2 - y1)
+    if (plain) return __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
     return __fmul_rn(__fadd_rn(__fsub_rn(x2, x1), 1.f), __fadd_rn(__fsub_rn(y2, y1), 1.f));
 }
 
@@ -175,7 +176,9 @@ __device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2
 // ovr >= thresh (thresh a double; nms_kernel.cu:71 has ovr > thresh).  Both reduce to ovr >= b for one
 // fp32 b (make_rule).  (A division-free form -- inter vs m*uni in double, m the rounding midpoint below b --
 // is exact too but measured 15-20 % slower than v_div on gfx950: fp64 converts and compares are not full rate.)
-struct NmsRule { float b; };
+// plain = 1: the torch NMS of layers/box_utils.py:229-293 (DetectOTA): no "+1", union = (area_j - inter) + area_i,
+// a candidate survives iff IoU <= overlap in fp32 (so a NaN IoU -- two zero-area boxes -- suppresses, like idx[IoU.le()]).
+struct NmsRule { float b; int plain; };
 static NmsRule make_rule(double thresh, int strict_gt)
 {
     float b = (float)thresh;
@@ -185,13 +188,18 @@ static NmsRule make_rule(double thresh, int strict_gt)
     } else if ((double)b < thresh) {      // (double)ovr >= thresh  <=>  ovr >= smallest fp32 >= thresh
         b = nextafterf(b, INFINITY);
     }
-    return NmsRule{b};
+    return NmsRule{b, 0};
 }
 // i = the kept (higher-score) box, j = the candidate
 __device__ __forceinline__ bool suppresses(const Box &i, const Box &j, const NmsRule &r)
 {
     const float xx1 = fmaxf(i.x1, j.x1), yy1 = fmaxf(i.y1, j.y1);
     const float xx2 = fminf(i.x2, j.x2), yy2 = fminf(i.y2, j.y2);
+    if (r.plain) {
+        const float w = fmaxf(__fsub_rn(xx2, xx1), 0.f), h = fmaxf(__fsub_rn(yy2, yy1), 0.f);
+        const float inter = __fmul_rn(w, h);
+        return !(__fdiv_rn(inter, __fadd_rn(__fsub_rn(j.area, inter), i.area)) <= r.b);
+    }
     const float w = fmaxf(0.f, __fadd_rn(__fsub_rn(xx2, xx1), 1.f));
     const float h = fmaxf(0.f, __fadd_rn(__fsub_rn(yy2, yy1), 1.f));
     const float inter = __fmul_rn(w, h);
@@ -644,9 +652,10 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
 
 // ---- stand-alone NMS (cpu_nms / gpu_nms twins): one workgroup, keep list in global memory ------
 // sort key of box i: (score key | presorted: descending rank) : ~index
-__device__ __forceinline__ unsigned long long nms_key(const float *__restrict__ dets, int n, int presorted, int i)
+__device__ __forceinline__ unsigned long long nms_key(const float *__restrict__ dets, int n, int presorted, int i, float min_score = -INFINITY)
 {
     if (i >= n) return 0ull;
+    if (!presorted && !(dets[(size_t)i * 5 + 4] > min_score)) return 0ull;       // not a candidate: sorts behind every candidate
     // presorted: keep the caller's order (gpu_nms.pyx:25-28 sorts on the host)
     const unsigned hi = presorted ? (unsigned)(n - i) : score_key(dets[(size_t)i * 5 + 4]);
     return ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
@@ -657,26 +666,31 @@ template <bool GK>
 __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict__ dets, int n, NmsRule rule, int presorted,
                                                         const unsigned long long *__restrict__ gkeys,
                                                         void *__restrict__ kept_mem, int *__restrict__ keep_out,
-                                                        int *__restrict__ num_out)
+                                                        int *__restrict__ num_out, float min_score, int pre_top_k)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];     // (no static LDS beside it: cdna guide G17)
     const unsigned long long *sk = GK ? gkeys : dsm;
     if constexpr (!GK) {
         int N = 64;
         while (N < n) N <<= 1;
-        for (int i = threadIdx.x; i < N; i += 256) dsm[i] = nms_key(dets, n, presorted, i);
+        for (int i = threadIdx.x; i < N; i += 256) dsm[i] = nms_key(dets, n, presorted, i, min_score);
         __syncthreads();
         if (!presorted) bitonic_sort_desc(dsm, N, threadIdx.x, 256);
     }
+    __syncthreads();
     if (threadIdx.x >= 64) return;
-    const KeepList kept(kept_mem, n);
+    int n_cand = 0;     // candidates = the non-zero keys (they sort first); at most pre_top_k of them enter the NMS (box_utils.py:251)
+    for (int i = threadIdx.x; i < n; i += 64) n_cand += sk[i] != 0ull ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
+    n = pre_top_k > 0 && n_cand > pre_top_k ? pre_top_k : n_cand;
+    const KeepList kept(kept_mem, n > 0 ? n : 1);
     const int nk = wave_greedy_nms(
         n, n, rule, kept,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
             const float *d = dets + (size_t)p * 5;
             bx.x1 = d[0]; bx.y1 = d[1]; bx.x2 = d[2]; bx.y2 = d[3];
-            bx.area = box_area(d[0], d[1], d[2], d[3]);
+            bx.area = box_area(d[0], d[1], d[2], d[3], rule.plain);
         },
         [&](int slot, int pos) { keep_out[slot] = (int)(0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull)); });
     if (threadIdx.x == 0) *num_out = nk;
@@ -688,11 +702,11 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict_
 // below that are finished tile by tile in LDS again.
 constexpr int kSortTile = 4096;
 __global__ __launch_bounds__(256) void nms_tile_sort_kernel(const float *__restrict__ dets, int n, int presorted, int do_sort,
-                                                            unsigned long long *__restrict__ keys)
+                                                            unsigned long long *__restrict__ keys, float min_score)
 {
     __shared__ unsigned long long t[kSortTile];
     const int base = blockIdx.x * kSortTile;
-    for (int i = threadIdx.x; i < kSortTile; i += 256) t[i] = nms_key(dets, n, presorted, base + i);
+    for (int i = threadIdx.x; i < kSortTile; i += 256) t[i] = nms_key(dets, n, presorted, base + i, min_score);
     __syncthreads();
     if (do_sort)
         for (int kk = 2; kk <= kSortTile; kk <<= 1)
@@ -733,24 +747,26 @@ size_t nms_workspace_bytes(int n)
     return b;
 }
 
+// plain_rule = 1: the torch NMS of layers/box_utils.py:229-293 (fp32 `thresh`, IoU <= thresh survives, no "+1"); min_score:
+// boxes with score <= min_score are no candidates; pre_top_k > 0: only the pre_top_k best candidates enter (box_utils.py:251)
 int launch_nms(const float *dets, int n, double thresh, int strict_gt, int presorted, int32_t *keep_out, int32_t *num_out,
-               void *ws, size_t ws_bytes, hipStream_t s)
+               void *ws, size_t ws_bytes, hipStream_t s, int plain_rule, float min_score, int pre_top_k)
 {
     if (!num_out || n < 0) return TDRN_E_ARG;
     if (n == 0) return hip_status(hipMemsetAsync(num_out, 0, sizeof(int), s));
     if (!dets || !keep_out || !ws) return TDRN_E_ARG;
     if (ws_bytes < nms_workspace_bytes(n)) return TDRN_E_WORKSPACE;
     const int N = next_pow2(n);
-    const NmsRule rule = make_rule(thresh, strict_gt);
+    const NmsRule rule = plain_rule ? NmsRule{(float)thresh, 1} : make_rule(thresh, strict_gt);
     if (n <= kNmsLdsKeys) {
         TDRN_TRY(allow_big_lds((const void *)nms_plain_kernel<false>));
         hipLaunchKernelGGL(nms_plain_kernel<false>, dim3(1), dim3(256), (size_t)N * 8, s, dets, n, rule, presorted,
-                           (const unsigned long long *)nullptr, ws, keep_out, num_out);
+                           (const unsigned long long *)nullptr, ws, keep_out, num_out, min_score, pre_top_k);
         return hip_status(hipGetLastError());
     }
     unsigned long long *keys = (unsigned long long *)((char *)ws + nms_kept_bytes(n));
     const int tiles = N / kSortTile;
-    hipLaunchKernelGGL(nms_tile_sort_kernel, dim3(tiles), dim3(256), 0, s, dets, n, presorted, presorted ? 0 : 1, keys);
+    hipLaunchKernelGGL(nms_tile_sort_kernel, dim3(tiles), dim3(256), 0, s, dets, n, presorted, presorted ? 0 : 1, keys, min_score);
     if (!presorted)
         for (int kk = 2 * kSortTile; kk <= N; kk <<= 1) {
             for (int j = kk >> 1; j >= kSortTile; j >>= 1)
@@ -758,7 +774,7 @@ int launch_nms(const float *dets, int n, double thresh, int strict_gt, int preso
             hipLaunchKernelGGL(nms_tile_merge_kernel, dim3(tiles), dim3(256), 0, s, keys, kk);
         }
     hipLaunchKernelGGL(nms_plain_kernel<true>, dim3(1), dim3(256), 0, s, dets, n, rule, presorted, (const unsigned long long *)keys, ws,
-                       keep_out, num_out);
+                       keep_out, num_out, min_score, pre_top_k);
     return hip_status(hipGetLastError());
 }
 

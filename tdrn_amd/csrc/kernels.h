@@ -1,5 +1,7 @@
 // kernels.h -- launch interfaces of the HIP kernels (internal to libtdrn_hip).
 #pragma once
+#include <cmath>
+
 #include "common.h"
 
 namespace tdrn {
@@ -131,6 +133,7 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
                   hipStream_t s);
 size_t nms_workspace_bytes(int n);
 int launch_nms(const float *dets, int n, double thresh, int strict_gt, int presorted,
-               int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s);
+               int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s,
+               int plain_rule = 0, float min_score = -INFINITY, int pre_top_k = 0);
 
 }  // namespace tdrn

@@ -1,0 +1,176 @@
+"""DetectOTA: drop-in for layers/functions/detection_ota.py:7-179 -- Detect with online tubelet association for video
+(`tub` > 0 links detections across frames by box IoU x ROI-feature cosine similarity and gives them identities).
+
+Split like the reference's own cost profile: what touches every prior runs on the device through the C ABI -- the
+two-stage decode (tdrn_decode / tdrn_center_size) and the per-class NMS with box_utils.nms's rule (tdrn_nms_topk:
+normalised boxes, no "+1", top_k best candidates only, IoU <= overlap survives) -- while the tubelet bookkeeping on the
+handful of survivors (python dictionaries in the reference too) stays host-driven, with its small tensors on the GPU.
+
+State (per class): tubelets[cl] = {identity: [tube, hold]} with tube = (<= tub, 5 + F) rows [score, box, roi feature],
+newest first, and hold = frames the tubelet survives without a match (loss_hold_len = 10); ides[cl] = their keys.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ... import _lib
+from ..box_utils import center_size, decode
+
+
+def _nms_topk(dets, overlap, min_score, top_k, ws_cache):
+    """layers/box_utils.py:229-293 on the device: dets (n,5) [x1,y1,x2,y2,score] -> (keep indices tensor, count)."""
+    lib = _lib.lib()
+    n = dets.size(0)
+    dev = dets.device
+    nb = lib.tdrn_nms_workspace_bytes(n)
+    ws = ws_cache.get("ws")
+    if ws is None or ws.numel() < nb or ws.device != dev:
+        ws = ws_cache["ws"] = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ws_cache["keep"] = torch.empty(n, dtype=torch.int32, device=dev)
+        ws_cache["num"] = torch.zeros(1, dtype=torch.int32, device=dev)
+    keep, num = ws_cache["keep"], ws_cache["num"]
+    if keep.numel() < n:
+        keep = ws_cache["keep"] = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(lib.tdrn_nms_topk(_lib.ptr(dets), n, float(overlap), float(min_score), int(top_k), _lib.ptr(keep), _lib.ptr(num),
+                                 _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "tdrn_nms_topk")
+    count = int(num.item())
+    return keep[:count].long(), count
+
+
+class Detect(object):
+    def __init__(self, num_classes, bkg_label, top_k, conf_thresh, nms_thresh, tub=0, tub_thresh=1.0,
+                 tub_generate_score=0.7, device='cuda'):
+        self.num_classes = num_classes
+        self.background_label = bkg_label
+        self.top_k = top_k
+        self.nms_thresh = nms_thresh
+        if nms_thresh <= 0:
+            raise ValueError('nms_threshold must be non negative.')
+        self.conf_thresh = conf_thresh
+        self.variance = [0.1, 0.2]
+        self.tub = tub
+        self.device = device
+        self.tub_thresh = tub_thresh
+        self.loss_hold_len = 10
+        self.tub_generate_score = tub_generate_score
+        self.tub_feature_size = 7
+        self._ws = {}
+        self.init_tubelets()
+
+    # ---- tubelet state (detection_ota.py:157-179) --------------------------------------------------------------
+    def init_tubelets(self):
+        if self.tub > 0:
+            self.tubelets = [dict() for _ in range(self.num_classes)]
+            self.ides = [None for _ in self.tubelets]
+            self.history_max_ides = [-1 for _ in range(self.num_classes)]
+
+    def delete_tubelets(self, cl):
+        """One frame has passed for class cl: every tubelet loses one unit of hold time; the expired ones go."""
+        gone = []
+        for ide, tubelet in self.tubelets[cl].items():
+            tubelet[-1] -= 1
+            if not tubelet[-1]:
+                gone.append(ide)
+        for ide in gone:
+            del self.tubelets[cl][ide]
+        self.ides[cl] = torch.tensor([float(k) for k in self.tubelets[cl].keys()], dtype=torch.float32, device=self._dev)
+
+    # ---- association pieces (layers/box_utils.py:295-367) --------------------------------------------------------
+    def _roi_feature(self, feature, box):
+        """:86-93: the box's cell range on the feature map, resampled to 7x7 (bilinear, align_corners) and flattened."""
+        Hf, Wf = feature.size(-2), feature.size(-1)
+        b = box.tolist()
+        x0 = int(np.clip(np.floor(b[0] * Wf), 0, Wf)); y0 = int(np.clip(np.floor(b[1] * Hf), 0, Hf))
+        x1 = int(np.clip(np.ceil(b[2] * Wf), 0, Wf)); y1 = int(np.clip(np.ceil(b[3] * Hf), 0, Hf))
+        s = self.tub_feature_size
+        return F.interpolate(feature[:, :, y0:y1, x0:x1], (s, s), mode='bilinear', align_corners=True).reshape(-1, s * s * feature.size(1))
+
+    @staticmethod
+    def _iou_to_tubelets(boxes, heads):
+        """box_utils.IoU: boxes (n,4) against the newest [score, box] row of every tubelet (m,5) -> (n,m); no "+1"."""
+        x1 = torch.maximum(boxes[:, None, 0], heads[None, :, 1]); y1 = torch.maximum(boxes[:, None, 1], heads[None, :, 2])
+        x2 = torch.minimum(boxes[:, None, 2], heads[None, :, 3]); y2 = torch.minimum(boxes[:, None, 3], heads[None, :, 4])
+        inter = (x2 - x1).clamp(min=0.0) * (y2 - y1).clamp(min=0.0)
+        area = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))[:, None]
+        area_t = ((heads[:, 3] - heads[:, 1]) * (heads[:, 4] - heads[:, 2]))[None, :]
+        return inter / ((area - inter) + area_t)
+
+    @staticmethod
+    def _cos_to_tubelets(feats, tubelets):
+        """box_utils.cos_similarity: mean over a tubelet's stored rows of the cosine between the roi and that row."""
+        roi = torch.cat(feats, 0)                                             # (n, F)
+        rn = roi.norm(2, dim=1)
+        cols = []
+        for _, (tube, _hold) in tubelets.items():
+            tf = tube[:, 5:]                                                  # (t, F)
+            cols.append(((roi @ tf.t()) / (rn[:, None] * tf.norm(2, dim=1)[None, :])).mean(dim=1))
+        return torch.stack(cols, 1)
+
+    def forward(self, loc_data, conf_data, prior_data, feature=None, arm_loc_data=None):
+        """loc (B,P,4), conf (B*P,C), priors (P,4), feature (1,Cf,Hf,Wf) when tub > 0, arm_loc (B,P,4)|None.
+        Returns (B, C, top_k, 5) rows [score, box] -- or (1, C, top_k, 6) rows [score, box, identity] when tub > 0
+        (identity -1 = not linked).  With tub > 0 the batch must be one frame (the reference's video loop)."""
+        _lib.require_cuda(loc_data, "loc_data")
+        dev = self._dev = loc_data.device
+        num, P, C = loc_data.size(0), prior_data.size(0), self.num_classes
+        if self.tub > 0 and num != 1:
+            raise ValueError("tubelet linking works on one frame at a time")
+        width = 6 if self.tub > 0 else 5
+        out = torch.zeros(num, C, self.top_k, width, device=dev)
+        conf = conf_data.contiguous().float().view(num, P, C)
+        pri = prior_data.to(dev).contiguous().float()
+        for i in range(num):
+            anchors = pri
+            if arm_loc_data is not None:
+                anchors = center_size(decode(arm_loc_data[i], pri, self.variance))
+            boxes = decode(loc_data[i], anchors, self.variance)                 # (P,4) normalised
+            for cl in range(1, C):
+                scores = conf[i, :, cl]
+                dets = torch.cat((boxes, scores[:, None]), 1).contiguous()
+                ids, count = _nms_topk(dets, self.nms_thresh, self.conf_thresh, self.top_k, self._ws)
+                if count == 0:                                                # no score above conf_thresh (:70-73)
+                    if self.tub > 0:
+                        self.delete_tubelets(cl)
+                    continue
+                nms_score, nms_box = scores[ids], boxes[ids]
+                if self.tub == 0:
+                    out[i, cl, :count] = torch.cat((nms_score[:, None], nms_box), 1)
+                    continue
+                feats = [self._roi_feature(feature, b) for b in nms_box]
+                identity = torch.full((count,), -1.0, device=dev)
+                tubes = self.tubelets[cl]
+                if tubes:
+                    heads = torch.stack([t[0][0, :5] for t in tubes.values()], 0)
+                    sim = torch.exp(self._iou_to_tubelets(nms_box, heads)) * self._cos_to_tubelets(feats, tubes)
+                    sim_max, sim_idx = sim.max(dim=1)
+                    # detections claiming the same tubelet: only the most similar one keeps its claim (:101-110)
+                    claim = sim_idx.tolist()
+                    for t in set(claim):
+                        rivals = [k for k, v in enumerate(claim) if v == t]
+                        if len(rivals) > 1:
+                            best = rivals[int(torch.argmax(sim_max[rivals]))]
+                            for k in rivals:
+                                if k != best:
+                                    sim_max[k] = 0.0
+                    matched = sim_max > self.tub_thresh
+                    if bool(matched.any()):
+                        identity[matched] = self.ides[cl].index_select(0, sim_idx[matched])
+                generate = (identity == -1) & (nms_score > self.tub_generate_score)
+                n_new = int(generate.sum())
+                if n_new > 0:                                                 # fresh identities continue the class's counter
+                    first = 0 if self.history_max_ides[cl] < 0 else int(self.history_max_ides[cl]) + 1
+                    identity[generate] = torch.arange(first, first + n_new, device=dev, dtype=torch.float32)
+                    self.history_max_ides[cl] = first + n_new - 1
+                out[i, cl, :count] = torch.cat((nms_score[:, None], nms_box, identity[:, None]), 1)
+                for row, fea, ide in zip(out[i, cl, :count], feats, identity.tolist()):
+                    if ide < 0:
+                        continue
+                    info = torch.cat((row[:-1].clone()[None, :], fea), dim=1)   # [score, box, roi feature]
+                    key = int(ide)
+                    if key in tubes:
+                        info = torch.cat((info, tubes[key][0]), 0)[:self.tub]
+                    tubes[key] = [info, self.loss_hold_len + 1]
+                self.delete_tubelets(cl)
+        return out
+
+    __call__ = forward

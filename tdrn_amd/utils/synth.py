@@ -84,3 +84,30 @@ def synth_detect_inputs(batch, num_priors, num_classes=21, bias=8.0, seed=1):
     e = np.exp(logits - logits.max(1, keepdims=True))
     conf = (e / e.sum(1, keepdims=True)).astype(np.float32)
     return loc, arm, conf
+
+
+def synth_ota_sequence(n_frames, num_priors=6375, num_classes=21, feat_shape=(1, 16, 40, 40)):
+    """A short synthetic video for DetectOTA (tubelet linking): per frame (loc (1,P,4), conf (P,C), arm_loc (1,P,4),
+    feature (1,Cf,Hf,Wf)).  Sparse background candidates (D9 regime) plus ten strong, slowly jittering detections in
+    each of five classes; class 7 loses six of them after frame 1, class 4 gains four at frame 5, class 12 gets the
+    sibling anchors (other aspect ratio, same cell) of three objects from frame 6 on."""
+    loc, arm, conf0 = synth_detect_inputs(1, num_priors, num_classes, 9.0, seed=1)
+    r = _rng("ota", 5)
+    feat0 = r.standard_normal(feat_shape).astype(np.float32)
+    strong = {c: r.choice(num_priors // 3, 10, replace=False) * 3 + 1 for c in (1, 4, 7, 12, 20)}     # anchor 1 (ar 2) of a cell
+    late4 = r.choice(num_priors // 3, 4, replace=False) * 3 + 1
+    base_score = {c: (0.35 + 0.5 * r.random(len(v))).astype(np.float32) for c, v in strong.items()}
+    frames = []
+    for t in range(n_frames):
+        conf = conf0.copy()
+        for c, idx in strong.items():
+            keep = slice(None) if (t < 2 or c != 7) else slice(0, 4)
+            conf[idx[keep], c] = base_score[c][keep] + np.float32(0.002) * r.standard_normal(len(idx[keep])).astype(np.float32)
+        if t >= 5:
+            conf[late4, 4] = np.float32(0.6) + np.float32(0.01) * np.arange(4, dtype=np.float32)
+        if t >= 6:
+            conf[strong[12][:3] + 1, 12] = base_score[12][:3] - np.float32(0.05)                          # anchor 2 (ar 1/2)
+        l = loc + np.float32(0.003) * r.standard_normal(loc.shape).astype(np.float32)
+        f = feat0 + np.float32(0.02) * r.standard_normal(feat_shape).astype(np.float32)
+        frames.append((l.astype(np.float32), conf.astype(np.float32), arm, f.astype(np.float32)))
+    return frames

@@ -325,3 +325,76 @@ def test_preprocess_matches_oracle_bit_exact(shape, size, rgb):
     if shape == (320, 320):        # identity resize: exactly pixel - mean
         exp = frames.astype(np.float32) - np.asarray(MEANS, np.float32)
         assert np.array_equal(got, exp[..., ::-1].transpose(0, 3, 1, 2) if rgb else exp.transpose(0, 3, 1, 2))
+
+
+# ---------------------------------------------------------------------------------------------
+# DetectOTA (second half): fixture = the reference class run over a synthetic video
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tub", [3, 0])
+def test_detect_ota_matches_reference_sequence(golden_dir, tub):
+    """layers/functions/detection_ota.py:37-179 over 14 frames: identities are created, carried across frames, expire
+    ten frames after their object vanished (class 7), new objects continue the class's counter (class 4), sibling
+    anchors become tubelets of their own (class 12).  Scores / boxes / identities per slot equal the reference's."""
+    from tdrn_amd.layers import DetectOTA
+    g = np.load(os.path.join(golden_dir, "detect_ota.npz"))
+    ref = g["tub%d" % tub]
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    det = DetectOTA(21, 0, 200, 0.01, 0.45, tub=tub, tub_thresh=1.0, tub_generate_score=0.1)
+    frames = synth.synth_ota_sequence(int(g["frames"]))
+    for t, (loc, conf, arm, feat) in enumerate(frames):
+        out = det.forward(_cu(loc), _cu(conf), pri, feature=_cu(feat), arm_loc_data=_cu(arm)).cpu().numpy()
+        assert out.shape == ref[t].shape == (1, 21, 200, 6 if tub else 5)
+        assert np.array_equal(out[..., 0] > 0, ref[t][..., 0] > 0), "frame %d: slot occupancy" % t
+        np.testing.assert_allclose(out[..., :5], ref[t][..., :5], rtol=3e-6, atol=1e-6, err_msg="frame %d" % t)
+        if tub:
+            assert np.array_equal(out[..., 5], ref[t][..., 5]), "frame %d: identities" % t
+    if tub:
+        assert [len(d) for d in det.tubelets if len(d)] == [9, 14, 4, 13, 10]
+        det.init_tubelets()
+        assert not any(det.tubelets)
+    with pytest.raises(ValueError):
+        DetectOTA(21, 0, 200, 0.01, 0.0)
+
+
+def test_nms_topk_is_box_utils_nms():
+    """tdrn_nms_topk against a numpy restatement of layers/box_utils.py:229-293 written in the test (no "+1", top_k
+    prefilter, IoU <= overlap survives, fp32), incl. the candidate threshold and a degenerate (zero-area) pair."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    n = 900
+    xy = rng.uniform(0, 0.8, (n, 2)).astype(np.float32)
+    wh = rng.uniform(0.02, 0.3, (n, 2)).astype(np.float32)
+    sc = (rng.permutation(n).astype(np.float32) / np.float32(n)).astype(np.float32)
+    dets = np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32)
+    dets[5, :4] = dets[6, :4] = np.float32(0.5)                      # two identical zero-area boxes: IoU = 0/0 = NaN -> suppressed
+    dets[5, 4], dets[6, 4] = np.float32(0.9905), np.float32(0.9795)      # (tie-free: equal scores have no defined order)
+
+    def ref_nms(d, overlap, min_score, top_k):
+        cand = np.nonzero(d[:, 4] > min_score)[0]
+        order = cand[np.argsort(d[cand, 4], kind="stable")][-top_k:] if top_k else cand[np.argsort(d[cand, 4], kind="stable")]
+        area = (d[:, 2] - d[:, 0]) * (d[:, 3] - d[:, 1])
+        keep = []
+        idx = order
+        while idx.size:
+            i = idx[-1]
+            keep.append(int(i))
+            idx = idx[:-1]
+            if not idx.size:
+                break
+            w = np.maximum(np.minimum(d[idx, 2], d[i, 2]) - np.maximum(d[idx, 0], d[i, 0]), np.float32(0))
+            h = np.maximum(np.minimum(d[idx, 3], d[i, 3]) - np.maximum(d[idx, 1], d[i, 1]), np.float32(0))
+            inter = w * h
+            with np.errstate(invalid="ignore", divide="ignore"):
+                iou = inter / ((area[idx] - inter) + area[i])
+            idx = idx[iou <= np.float32(overlap)]
+        return keep
+    lib = _lib.lib()
+    d = _cu(dets)
+    keep = torch.empty(n, dtype=torch.int32, device=DEV)
+    num = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nb = lib.tdrn_nms_workspace_bytes(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    for overlap, min_score, top_k in ((0.45, 0.01, 200), (0.3, 0.5, 200), (0.6, -1.0, 0), (0.45, 2.0, 200)):
+        _lib.check(lib.tdrn_nms_topk(_lib.ptr(d), n, overlap, min_score, top_k, _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws), nb, None))
+        torch.cuda.synchronize()
+        got = keep[: int(num.item())].cpu().tolist()
+        assert got == ref_nms(dets, overlap, min_score, top_k), (overlap, min_score, top_k)
