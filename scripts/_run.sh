@@ -1,2 +1,4 @@
 mkdir -p gpurun_out/r2
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "ota or topk or nms or detect" > gpurun_out/r2/t_ota.log 2>&1
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r2/t_all.log 2>&1
+python scripts/drift_table.py --out gpurun_out/r2/drift > gpurun_out/r2/drift.log 2>&1
+python bench.py --per-op > gpurun_out/r2/bench_d.json 2> gpurun_out/r2/bench_d.err

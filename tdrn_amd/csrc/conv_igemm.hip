@@ -36,6 +36,7 @@ struct ConvParams {
     int splits;       // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to `partial`
     float *partial;   // [splits][phases][M][Npad] fp32
     int ablate;   // diagnostics only (TDRN_CONV_ABLATE): 1 = skip the K-loop loads, 2 = skip the MFMAs
+    int batch_minor, B;   // batch_minor: GEMM row m = (ho*Wo + wo)*B + b instead of (b*Ho + ho)*Wo + wo (see conv_igemm_kernel)
 };
 
 template <typename DT> struct Mma;
@@ -102,6 +103,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     const char *wbase = p.w + (size_t)z * p.Npad * p.Ktot * ES;
     const long long obase = p.o_base + (z >> 1) * p.o_pr + (z & 1) * p.o_pc;
     const int HoWo = p.Ho * p.Wo;
+    // GEMM row -> (image, pixel).  Small maps with padding use the batch-minor order: the 128 / 256 rows of a tile are
+    // then the same few pixel positions of many images, so a tap that falls into the padding does so for the WHOLE tile
+    // and its K-steps are skipped (loads and MFMAs): fc6 (3x3, dilation 6 on a 10x10 map) has 64 % of its (pixel, tap)
+    // pairs in the padding.  A skipped step would have added exact zeros, so results are bit-identical either way.
+    auto decode = [&](int m, int &b, int &rem) {
+        if (p.batch_minor) { rem = m / p.B; b = m - rem * p.B; }
+        else { b = m / HoWo; rem = m - b * HoWo; }
+    };
 
     // per-thread pixel rows of the activation tile
     int hi0[PA], wi0[PA], pbase[PA];
@@ -109,7 +118,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     for (int i = 0; i < PA; ++i) {
         const int m = m0 + i * RPP + lrow;
         if (m < p.M) {
-            const int b = m / HoWo, rem = m - b * HoWo;
+            int b, rem;
+            decode(m, b, rem);
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             hi0[i] = ho * p.stride - p.pad;
             wi0[i] = wo * p.stride - p.pad;
@@ -147,12 +157,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
             glds16(ok ? p.in + off : p.zero, sb + BN * 128 + (i * RPP + wave * 8) * 128);
         }
     };
+    // taps that touch the image for at least one row of this tile (bit = tr*kw + tq); all ones without padding
+    unsigned tapmask = 0xFFFFFFFFu;
+    if (p.pad > 0 && p.kh * p.kw <= 32) {
+        unsigned mine = 0u;
+        for (int a = 0; a < p.kh; ++a)
+            for (int c = 0; c < p.kw; ++c) {
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < PA; ++i)
+                    any |= (unsigned)(hi0[i] + a * p.dil) < (unsigned)p.H && (unsigned)(wi0[i] + c * p.dil) < (unsigned)p.W;
+                if (any) mine |= 1u << (a * p.kw + c);
+            }
+        for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor(mine, o, 64);
+        unsigned *mk = (unsigned *)smem;
+        if (t == 0) *mk = 0u;
+        __syncthreads();
+        if (lane == 0) atomicOr(mk, mine);
+        __syncthreads();
+        tapmask = *mk;
+        __syncthreads();                     // (the first stage() overwrites this word)
+    }
     auto advance = [&]() {
         c0 += CK;
         kofs += CK;
         if (c0 == p.Cin) {
             c0 = 0;
-            if (++tq == p.kw) { tq = 0; ++tr; }
+            do {                             // on to the next tap that is not all padding (the caller knows there is one)
+                if (++tq == p.kw) { tq = 0; ++tr; }
+                if (p.kh * p.kw > 32 || ((tapmask >> ((tr * p.kw + tq) & 31)) & 1u)) break;
+                kofs += p.Cin;
+            } while (tr < p.kh);
         }
     };
 
@@ -180,17 +215,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     };
 
     int nk = p.kh * p.kw * (p.Cin / CK);
-    if (p.splits > 1) {
-        // this workgroup's K slice [ks0, ks1): position the (tap, channel) cursor at ks0
-        const int per = (nk + p.splits - 1) / p.splits;
-        const int ks0 = blockIdx.y * per, ks1 = min(nk, ks0 + per);
+    {
+        // this workgroup's K slice [ks0, ks1) of the FULL step sequence (split boundaries never depend on what is
+        // skipped: a frame's partial sums must not depend on the batch it travels in); inside it only the steps of
+        // live taps run.  Position the (tap, channel) cursor at the first live step.
+        const int per = p.splits > 1 ? (nk + p.splits - 1) / p.splits : nk;
+        const int ks0 = p.splits > 1 ? blockIdx.y * per : 0, ks1 = min(nk, ks0 + per);
         const int cpt = p.Cin / CK;                  // K-steps per tap
-        const int tap0 = ks0 / cpt;
+        int live = 0, first = -1;
+        for (int tap = ks0 / cpt; tap * cpt < ks1; ++tap) {
+            if (p.kh * p.kw <= 32 && !((tapmask >> tap) & 1u)) continue;
+            const int a = max(ks0, tap * cpt), e = min(ks1, (tap + 1) * cpt);
+            if (first < 0) first = a;
+            live += e - a;
+        }
+        nk = live;
+        if (first < 0) first = ks0;
+        const int tap0 = first / cpt;
         tr = tap0 / p.kw;
         tq = tap0 - tr * p.kw;
-        c0 = (ks0 - tap0 * cpt) * CK;
-        kofs = ks0 * CK;
-        nk = ks1 > ks0 ? ks1 - ks0 : 0;
+        c0 = (first - tap0 * cpt) * CK;
+        kofs = first * CK;
     }
     if constexpr (STAGES == 2) {
         if (nk > 0) stage(0);
@@ -277,7 +322,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
             const int row = idx / CPR, chn = idx - row * CPR;
             const int m = m0 + row, c = n0 + chn * 4;
             if (m >= p.M || c >= p.Cout) continue;
-            const int b = m / HoWo, rem = m - b * HoWo;
+            int b, rem;
+            decode(m, b, rem);
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             float *dst = (float *)p.out + obase + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
             f32x4 v = *(const f32x4 *)(smem + row * CS + chn * 16);
@@ -304,10 +350,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
                 const int m = m0 + row;
                 if (m >= p.M) break;
                 long long eo;
-                if (p.out_linear) {
+                if (p.out_linear && !p.batch_minor) {
                     eo = obase + (long long)m * p.o_cs + c;
                 } else {
-                    const int b = m / HoWo, rem = m - b * HoWo;
+                    int b, rem;
+                    decode(m, b, rem);
                     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
                     eo = obase + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
                 }
@@ -389,10 +436,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
         f32x4 v = *(const f32x4 *)(p.bias + c);
         for (int sidx = 0; sidx < p.splits; ++sidx) v += *(const f32x4 *)(src + sidx * slab);
         long long eo;
-        if (p.out_linear) {
+        if (p.out_linear && !p.batch_minor) {
             eo = p.o_base + (long long)m * p.o_cs + c;
         } else {
-            const int b = m / HoWo, rem = m - b * HoWo;
+            int b, rem;
+            if (p.batch_minor) { rem = m / p.B; b = m - rem * p.B; }
+            else { b = m / HoWo; rem = m - b * HoWo; }
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             eo = p.o_base + (z >> 1) * p.o_pr + (z & 1) * p.o_pc + b * p.o_bs + ho * p.o_rs + wo * p.o_cs + c;
         }
@@ -481,6 +530,12 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     p.out_linear = (!a.out_f32 && a.phases == 1 && a.o_rs == (long long)a.Wo * a.o_cs &&
                     a.o_bs == (long long)a.Ho * a.Wo * a.o_cs) ? 1 : 0;
     p.n_tiles = 0;
+    p.B = a.B;
+    {
+        static int bm = -1;                  // TDRN_IGEMM_BATCH_MINOR=0: keep the image-major row order (A/B switch)
+        if (bm < 0) { const char *e = getenv("TDRN_IGEMM_BATCH_MINOR"); bm = e ? atoi(e) : 1; }
+        p.batch_minor = (bm && a.pad > 0 && a.phases == 1 && a.B > 1 && a.Ho * a.Wo <= 1600 && a.kh * a.kw <= 32) ? 1 : 0;
+    }
     p.splits = (a.splitk > 1 && a.partial) ? a.splitk : 1;
     p.partial = (float *)a.partial;
     static int ablate = -1;

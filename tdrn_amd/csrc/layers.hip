@@ -6,6 +6,7 @@
 //   Softmax(dim=1)            model/dualrefinedet_vggbn.py:116-117,196
 //   offset 1x1 convs          model/dualrefinedet_vggbn.py:53-57,71-76,155-164
 #include <atomic>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -102,19 +103,43 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) char stage[4 * 32 * TS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r32 = lane & 31, hh = lane >> 5;
 
-    // A operand: lane (r32, hh) holds W[32*ci + r32][2*s + hh]; B operand: X[2*s + hh][pixel r32]
-    float wr[2][14];
-    int koff[14];                                        // LDS offset of my k of step s, relative to the pixel's halo origin
+    // fp32 mode: exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32, 14 steps of K = 2 per 32 couts): lane (r32, hh)
+    // holds W[32*ci + r32][2*s + hh] (A) and X[2*s + hh][pixel r32] (B).
+    // 16-bit modes: like every other layer, inputs and weights are rounded to the net dtype and accumulated in fp32
+    // (v_mfma_f32_32x32x16_*: K = 27 padded to 32 = two steps; lane (r32, hh) holds k = 16*ks + 8*hh + j, j = 0..7).
+    // (pixel - mean) of 8-bit frames are integers below 256: exact in bf16 and fp16.)  The fp32 matrix rate is 1/16 of
+    // the 16-bit one and made this layer MFMA-bound (28 x 64 cycles per 32 pixels x 64 couts, 81 us at batch 32) beside
+    // a 420-MB output; with 4 x 32 cycles it runs at the speed of its stores.
+    constexpr bool kHalf = ES == 2;
+    constexpr int NS = kHalf ? 16 : 14;                  // LDS reads of my pixel per output row
+    float wr[2][kHalf ? 1 : 14];
+    u32x4 wq[2][2];                                      // 16-bit modes: packed weights [ci][k-step]
+    int koff[NS];                                        // LDS offset of my k, relative to the pixel's halo origin
 #pragma unroll
-    for (int s2 = 0; s2 < 14; ++s2) {
-        const int k = 2 * s2 + hh;
+    for (int s2 = 0; s2 < NS; ++s2) {
+        const int k = kHalf ? 16 * (s2 >> 3) + 8 * hh + (s2 & 7) : 2 * s2 + hh;
         const int c = k / 9, r = (k - 9 * c) / 3, q = k - 9 * c - 3 * r;
-        koff[s2] = k < 27 ? (c * IH + r) * IW + q : 0;   // k = 27 is the zero pad of K: its weight is 0
+        koff[s2] = k < 27 ? (c * IH + r) * IW + q : 0;   // k >= 27 is the zero pad of K: its weight is 0
+        if constexpr (!kHalf) {
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci) {
-            const int co = ci * 32 + r32;
-            wr[ci][s2] = (k < 27 && co < Cout) ? w[co * 27 + k] : 0.f;
+            for (int ci = 0; ci < 2; ++ci) {
+                const int co = ci * 32 + r32;
+                wr[ci][s2] = (k < 27 && co < Cout) ? w[co * 27 + k] : 0.f;
+            }
         }
+    }
+    if constexpr (kHalf) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int co = ci * 32 + r32, k0 = 16 * ks + 8 * hh + 2 * jj;
+                    const float a = (k0 < 27 && co < Cout) ? w[co * 27 + k0] : 0.f;
+                    const float b2 = (k0 + 1 < 27 && co < Cout) ? w[co * 27 + k0 + 1] : 0.f;
+                    wq[ci][ks][jj] = pack2<typename std::conditional<kHalf, DT, bf16_t>::type>(a, b2);
+                }
     }
     // bias of the 64 couts in LDS (32 registers otherwise: they cost the fourth wave per SIMD)
     __shared__ __attribute__((aligned(16))) float bias_s[64];
@@ -175,14 +200,31 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const float *__res
                     for (int j = 0; j < 4; ++j) acc[ci][4 * g + j] = bv[j];
                 }
             const int porg = (orow * STRIDE) * IW + r32 * STRIDE;      // halo origin of my pixel
-            float xv[14];
+            float xv[NS];
 #pragma unroll
-            for (int s2 = 0; s2 < 14; ++s2) xv[s2] = xin[porg + koff[s2]];
+            for (int s2 = 0; s2 < NS; ++s2) xv[s2] = xin[porg + koff[s2]];
+            if constexpr (kHalf) {
+                typedef typename std::conditional<kHalf, DT, bf16_t>::type HT;
 #pragma unroll
-            for (int s2 = 0; s2 < 14; ++s2)
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 xq;
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
-                    acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[ci][s2], xv[s2], acc[ci], 0, 0, 0);
+                    for (int jj = 0; jj < 4; ++jj) xq[jj] = pack2<HT>(xv[8 * ks + 2 * jj], xv[8 * ks + 2 * jj + 1]);
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci) {
+                        if constexpr (__is_same(HT, bf16_t))
+                            acc[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(i16x8, wq[ci][ks]), __builtin_bit_cast(i16x8, xq), acc[ci], 0, 0, 0);
+                        else
+                            acc[ci] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq[ci][ks]), __builtin_bit_cast(f16x8, xq), acc[ci], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 14; ++s2)
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci)
+                        acc[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[ci][s2], xv[s2], acc[ci], 0, 0, 0);
+            }
             // ---- ReLU, convert, transpose through LDS, whole-line stores ----
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)

@@ -92,7 +92,7 @@ struct tdrn_net {
     int cur_lane = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
-    int splitk_ref_batch = 8;           // split-K factors are planned for this batch and used for every batch (TDRN_SPLITK_REF)
+    int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_zero = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
@@ -595,7 +595,7 @@ struct tdrn_net {
                 ops.insert(ops.begin() + (long)prod + 1, o);
             }
         }
-        if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 8;
+        if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 32;
         // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
         {
