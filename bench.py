@@ -243,7 +243,7 @@ def main():
         print("%-44s %11s %11s %8s %9s %8s" % ("launch", "alone us", "in step us", "GFLOP", "TFLOP/s", "GB"), file=sys.stderr)
         for o in ops:
             tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
-            print("%-44s %11.1f %11.1f %8.1f %9.1f %8.2f" % (o["name"], o["ms"] * 1e3, prod.get(o["name"], 0.0) * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
+            print("%-44s %11.1f %11.1f %8.1f %9.1f %8.3f" % (o["name"], o["ms"] * 1e3, prod.get(o["name"], 0.0) * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
     conv = max(stats_prod, key=lambda s: s["ms"])            # the dominant kernel family of the step
     solo = next(s for s in stats if s["name"] == conv["name"])
     peak = PEAK_TFLOPS[args.dtype]
