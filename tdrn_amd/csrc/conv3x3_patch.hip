@@ -26,6 +26,7 @@
 // loader zero-fills the halo outside the image), and "flat" tiles of 256 consecutive NHW pixels for
 // narrow maps (W <= 43: 40x40, 20x20), where the per-lane tap-validity mask zeroes fragments whose
 // tap falls outside the image.
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -54,7 +55,23 @@ struct PatchParams {
     int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
     int M;                         // B*H*W
     int ablate;                    // diagnostics (TDRN_CONV_ABLATE): 1 = loaders issue nothing, 2 = consumers skip ds_read+MFMA
+#ifdef TDRN_PATCH_STAMP
+    unsigned *stamps;              // diagnostics build only: [workgroup][wave][8] cycle sums (s_memtime), see the launcher
+#endif
 };
+
+// In-kernel cycle stamps of a diagnostics build (make EXTRA=-DTDRN_PATCH_STAMP; never in the product): where do the
+// loader and the consumer waves spend a step?  s_memtime returns through lgkmcnt, so the consumers stamp only where
+// they drain it anyway (before the step's barrier) and right behind the barrier / the last K slice.
+#ifdef TDRN_PATCH_STAMP
+#define STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(); unsigned st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += (unsigned)(t_ - st_t); st_t = t_; } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) p.stamps[((size_t)blockIdx.x * 12 + wave) * 8 + k_] = st_acc[k_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k) do { } while (0)
+#define STAMP_FLUSH do { } while (0)
+#endif
 
 namespace {
 
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         __builtin_amdgcn_s_barrier();
 
         int tap = 0, c_it = 0, c_cc = 0, carried = 0;
+        STAMP_DECL
         const int last_piece = lw + 4 * (kSlotsPerLoader - 1) < kPatchSlots ? 1 : 0;
         for (int g = 0; g < n_steps; ++g) {
             // operands of step g are in LDS.  Issue the weights of step g+2 and this tap's share of the
@@ -298,9 +316,12 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 issued += 1;
             }
             // ring of 3: everything issued before this step has landed; ring of 4: before the previous step
+            STAMP(0);                                       // issue
             wait_vmcnt(live ? issued + (RING == 4 ? carried : 0) : 0);
+            STAMP(1);                                       // landing of the previous step's pieces
             carried = issued;
             __builtin_amdgcn_s_barrier();
+            STAMP(2);                                       // barrier (waiting for the consumers)
             if (++tap == 9) {
                 tap = 0;
                 next_patch_chunk();
@@ -310,6 +331,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 }
             }
         }
+        STAMP_FLUSH;
         return;
     }
 
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         load_frags(wfA, pfA, 0);
     }
     int it = 0, cc = 0, tap = 0, tq = 0, delta = 0, wslot = 0, pbuf = 0;
+    STAMP_DECL
 #pragma unroll 1
     for (int g = 0; g < n_steps; ++g) {
         unsigned m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
@@ -555,8 +578,12 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(0);
         // every LDS read of this step has returned -> the step's buffers may be refilled after the barrier
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        STAMP(0);                                           // K slices 0-2: reads + 12 MFMAs + drain
         __builtin_amdgcn_s_barrier();
+        STAMP(1);                                           // barrier (waiting for the loaders / the other consumers)
         // ---- advance to step g+1 and start its first reads, THEN finish this step's last K-slice ----
+        // (measured and rejected: the cursor and the read addresses computed before the barrier, in the shadow of slice 2's
+        // MFMAs, so that only the four reads stand between the barrier and slice 3: -7 % on the family)
         const bool item_done = tap == 8 && cc == nchunks - 1;
         wslot = wslot == RING - 1 ? 0 : wslot + 1;
         ++tap;
@@ -581,6 +608,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(1);
         mma_frags(wfB, pfB, m0, m1);
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(0);
+        STAMP(2);                                           // K slice 3 under the next step's first reads
         if (item_done) {
             epilogue();
             ++it;
@@ -588,8 +616,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 setup_item(it);
                 init_acc(it);
             }
+            STAMP(3);                                       // epilogue + next item's set-up
         }
     }
+    STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -651,6 +681,36 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
     if (p.items <= 0) return TDRN_OK;
+#ifdef TDRN_PATCH_STAMP
+    // diagnostics build: synchronise after every launch and print the mean cycles per wave in each state
+    static unsigned *stamps = nullptr;
+    if (!stamps) TDRN_HIP_TRY(hipMalloc((void **)&stamps, 256 * 12 * 8 * sizeof(unsigned)));
+    TDRN_HIP_TRY(hipMemsetAsync(stamps, 0, 256 * 12 * 8 * sizeof(unsigned), s));
+    p.stamps = stamps;
+    struct Report {
+        const PatchParams &p; hipStream_t s; int BN, nchunks;
+        ~Report()
+        {
+            static unsigned host[256 * 12 * 8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(host, p.stamps, sizeof(host), hipMemcpyDeviceToHost);
+            double c[4] = {0, 0, 0, 0}, l[3] = {0, 0, 0};
+            int nc = 0, nl = 0;
+            for (int b = 0; b < 256; ++b)
+                for (int w = 0; w < 12; ++w) {
+                    const unsigned *v = host + (b * 12 + w) * 8;
+                    if (v[0] + v[1] + v[2] == 0) continue;
+                    if (w < 8) { for (int k = 0; k < 4; ++k) c[k] += v[k]; ++nc; }
+                    else { for (int k = 0; k < 3; ++k) l[k] += v[k]; ++nl; }
+                }
+            if (!nc || !nl) return;
+            const double steps = (double)((p.items + 255) / 256) * nchunks * 9;
+            fprintf(stderr, "patch_stamp H%d W%d Cin%d Cout%d BN%d tw%d items%d steps/CU~%.0f | consumer cyc/wave: slices0-2 %.0f barrier %.0f slice3 %.0f epilogue %.0f"
+                            " | loader cyc/wave: issue %.0f vmcnt %.0f barrier %.0f\n",
+                    p.H, p.W, p.Cin, p.Cout, BN, p.tw, p.items, steps, c[0] / nc, c[1] / nc, c[2] / nc, c[3] / nc, l[0] / nl, l[1] / nl, l[2] / nl);
+        }
+    } report{p, s, BN, (int)(p.Cin * dtype_bytes(a.dtype) / 128)};
+#endif
 #define LP(DT)                                                    \
     return BN == 128 ? launch_patch_cfg<DT, 128>(p, s) : launch_patch_cfg<DT, 64>(p, s)
     switch (a.dtype) {
