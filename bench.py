@@ -12,7 +12,10 @@ weak scaling, value = all ranks' frames / max-over-ranks time.
 
 The JSON line also carries
   roofline     : the dominant kernel family (conv3x3_patch_mfma): algorithmic FLOPs of its launches in one
-                 step / their summed hipEvent durations, against the dense bf16 MFMA peak
+                 step / their summed hipEvent durations IN THE PRODUCTION SCHEDULE (events recorded by the library on the
+                 stream each launch runs on, side lanes on), against the dense bf16 MFMA peak; `single_stream` gives the
+                 same with every launch alone on one stream; `traffic` = HBM-side bytes per launch from the committed
+                 rocprofv3 PMC passes (profiles/pmc_traffic.json)
   parity       : the other half of BASELINE's metric ("box L-inf vs CPU ref"): decoded boxes and softmax scores of
                  the TIMED dtype (and of the fp32 and fp16 modes beside it) against the fp32 CPU oracle on one frame
   cpu_baseline : the CPU oracle (torch-CPU convs + C deformable conv + C Detect) on a bounded sample
