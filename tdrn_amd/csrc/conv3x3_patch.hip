@@ -54,6 +54,7 @@ struct PatchParams {
     int tiles_x, tiles_per_img;    // 2-D mode
     int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
     int M;                         // B*H*W
+    int max_wgs;                   // > 0: cap on the persistent grid
     int ablate;                    // diagnostics (TDRN_CONV_ABLATE): 1 = loaders issue nothing, 2 = consumers skip ds_read+MFMA
 #ifdef TDRN_PATCH_STAMP
     unsigned *stamps;              // diagnostics build only: [workgroup][wave][8] cycle sums (s_memtime), see the launcher
@@ -640,7 +641,8 @@ int patch_conv_supported(const ConvArgs &a)
 template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p, hipStream_t s)
 {
     // a multiple of 8 workgroups (the item split is per XCD); surplus workgroups find no item and exit
-    const int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
+    int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
+    if (p.max_wgs > 0 && grid > p.max_wgs) grid = p.max_wgs;
     if (p.tw == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 0>), dim3(grid), dim3(768), 0, s, p);
     else if (p.tw == 32) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 32>), dim3(grid), dim3(768), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 16>), dim3(grid), dim3(768), 0, s, p);
@@ -680,6 +682,7 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
+    p.max_wgs = a.max_wgs > 0 ? (a.max_wgs / 8) * 8 : 0;
     if (p.items <= 0) return TDRN_OK;
 #ifdef TDRN_PATCH_STAMP
     // diagnostics build: synchronise after every launch and print the mean cycles per wave in each state

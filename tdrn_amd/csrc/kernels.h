@@ -36,6 +36,7 @@ struct ConvArgs {
     void *partial = nullptr;        // fp32 scratch of conv_splitk_bytes()
     long long o_bs = 0, o_rs = 0, o_cs = 0, o_base = 0, o_pr = 0, o_pc = 0;
     int dtype = TDRN_BF16;
+    int max_wgs = 0;                // patch kernel: > 0 caps the persistent grid (a multiple of 8), leaving CUs to concurrent lanes
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
 int conv_splitk_choice(const ConvArgs &a);          // 1 = no split

@@ -90,6 +90,12 @@ struct tdrn_net {
     static constexpr int kLanes = 4;
     size_t splitk_off[kLanes] = {0, 0, 0, 0};   // per-lane split-K slab region (bytes per sample from workspace start)
     int cur_lane = 0;
+    // Side-lane convs (TCB laterals, ARM heads, offset convs) are held back until conv5_3 has been computed: released on their
+    // true inputs (L2Norm of conv4_3) they share the CUs with conv5_1..5_3 and stretch the trunk, the critical path, by
+    // 0.24 ms; held back, they run beside conv6/conv7 and the small top-down layers instead (+1.4 % frames/s; held until fc7
+    // or capped to 128..224 workgroups: no further gain).  TDRN_LATE_SIDE 0: off, 2: until fc7; TDRN_SIDE_GRID: the cap.
+    int t_late = -1, t_late2 = -1;
+    int late_side = 1, side_grid = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
     int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
@@ -370,13 +376,14 @@ struct tdrn_net {
             idx += bn ? 3 : 2;
             ++nconv;
             if (nconv == 10) c43 = x;
-            if (nconv == 13) c53 = x;
+            if (nconv == 13) { c53 = x; t_late = x; }
         }
         x = pool(x, 0, true);   // pool5_ds (conv5_3 also feeds L2Norm_5_3)
         idx += 1;
         x = conv(x, "backbone." + std::to_string(idx), true, bn ? "backbone." + std::to_string(idx + 1) : "", 1024, 3, 1, 6, 6, 1);
         idx += bn ? 3 : 2;
         fc7 = conv(x, "backbone." + std::to_string(idx), true, bn ? "backbone." + std::to_string(idx + 1) : "", c7, 1, 1, 0, 1, 1);
+        t_late2 = fc7;
     }
 
     // TCB / FPN (dualrefinedet_vggbn.py:30-34,97-114,166-178).  Returns the 4 ODM sources.
@@ -595,6 +602,8 @@ struct tdrn_net {
                 ops.insert(ops.begin() + (long)prod + 1, o);
             }
         }
+        if (const char *e = getenv("TDRN_LATE_SIDE")) late_side = atoi(e);
+        if (const char *e = getenv("TDRN_SIDE_GRID")) side_grid = atoi(e);
         if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 32;
         // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
@@ -925,6 +934,10 @@ struct tdrn_net {
                 }
                 for (int t : {o.in, o.res, o.off_t})
                     if (t >= 0 && tensor_lane[t] != lane) TDRN_HIP_TRY(hipStreamWaitEvent(s, tensor_ev[t], 0));
+                if (late_side && lane != 0 && (o.kind == OP_CONV || o.kind == OP_OFFSET)) {
+                    const int tl = late_side == 2 ? t_late2 : t_late;
+                    if (tl >= 0 && tensor_shared[tl]) TDRN_HIP_TRY(hipStreamWaitEvent(s, tensor_ev[tl], 0));
+                }
             }
             const bool deform_batched = o.kind == OP_DEFORM && oi + 1 < ops.size() && ops[oi + 1].kind == OP_DEFORM && n_dargs < 3;
             if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) { TDRN_HIP_TRY(hipEventRecord(ev[evi], s)); }
@@ -941,6 +954,7 @@ struct tdrn_net {
                     a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
                     a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                     a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
+                    if (lane != 0) a.max_wgs = side_grid;
                     if (o.out_kind == OUT_TENSOR) {
                         const Tensor &to = tensors[o.out];
                         a.out = tptr(ws, o.out, B);

@@ -71,3 +71,31 @@ def test_nms_fuzz_matches_oracle(seed):
     thr = float(rng.choice([0.3, 0.5, 0.7]))
     for strict in (False, True):
         assert nms(dets, thr, force_cpu=not strict) == orc.cpu_nms(dets, thr, strict_gt=strict)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_deform_conv_fuzz_matches_oracle(seed):
+    """Random shape classes of the deformable op (per-axis kernel / stride / padding / dilation, groups, ragged channels,
+    offsets large enough to leave the map on every side) against deform_conv_cuda_kernel.cu's restatement, fp32."""
+    from tdrn_amd.model.networks import conv_offset2d
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    G = int(rng.choice([1, 1, 2, 4, 8]))
+    Cin = G * int(rng.choice([1, 2, 3, 8, 16, 32]))
+    Cout = int(rng.choice([1, 4, 12, 63, 75, 96, 130]))
+    kh, kw = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    sh, sw = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    dh, dw = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    ph, pw = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    N = int(rng.integers(1, 4))
+    H = int(rng.integers(dh * (kh - 1) + 1, dh * (kh - 1) + 14))
+    W = int(rng.integers(dw * (kw - 1) + 1, dw * (kw - 1) + 14))
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, kh, kw)) * (Cin * kh * kw) ** -0.5).astype(np.float32)
+    off = (float(rng.choice([0.0, 0.5, 2.0, 6.0])) * rng.standard_normal((N, G * 2 * kh * kw, Ho, Wo))).astype(np.float32)
+    ref = orc.deform_conv_forward(x, off, w, (sh, sw), (ph, pw), (dh, dw), G)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    got = conv_offset2d(t(x), t(off), t(w), (sh, sw), (ph, pw), (dh, dw), G).cpu().numpy()
+    assert got.shape == ref.shape == (N, Cout, Ho, Wo)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=3e-5)
