@@ -197,7 +197,8 @@ TDRN_API void tdrn_net_destroy(tdrn_net *net);
 
 /* state_dict interface: names and shapes are the reference's (entries ending in
  * num_batches_tracked are not parameters and are rejected with TDRN_E_PARAM).
- * tdrn_net_param_count/info enumerate what the plan expects, in the reference's order. */
+ * tdrn_net_param_count/info enumerate what the plan expects: the reference's names and shapes, in the order the plan
+ * consumes them (load by name, as load_state_dict does; the order carries no meaning). */
 TDRN_API int tdrn_net_param_count(const tdrn_net *net);
 TDRN_API int tdrn_net_param_info(const tdrn_net *net, int index, const char **name,
                                  int64_t shape[4], int *ndim);
