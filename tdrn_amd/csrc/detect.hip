@@ -285,52 +285,85 @@ __device__ __forceinline__ int wave_greedy_nms(int n, int cap, const NmsRule &r,
 // Workgroup version for Detect (256 threads), resumable: *nk_s boxes are already in `kept` on entry (the
 // caller zeroes it once) and the n candidates given continue the descending order.  Candidates are taken
 // 256 at a time; every thread first tests its candidate against the keep list as it stood at the start of
-// the round (the long scan, spread over 4 waves), then wave 0 settles the round 64 candidates at a time
-// against only the boxes kept DURING this round plus the pairwise bits.  Same decisions as the sequential
-// algorithm.  Returns min(*nk_s, cap).
+// the round (the long scan, spread over 4 waves), then against the earlier candidates of the same round (pairwise
+// bits, again on all 4 waves, the group's boxes handed round by v_readlane), and the greedy decisions are then pure
+// mask arithmetic, one 64-candidate group after the other.  Same decisions as the sequential algorithm.  (The bench
+// regime consumes ~300 candidates per class for 200 survivors: two rounds; the pair tests are VALU-throughput-bound
+// with 2.5 workgroups per CU.)  Returns min(*nk_s, cap).
 template <typename Get, typename Emit>
 __device__ __forceinline__ int block_greedy_nms(int n, int cap, const NmsRule &r, const KeepList &kept, unsigned char *alive_s,
-                                                int *nk_s, Get get, Emit emit)
+                                                int *nk_s, Box *rb, unsigned *kmw, Get get, Emit emit)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 256) {
+    for (int c0 = 0; c0 < n;) {
         const int nk0 = *nk_s;
         if (nk0 >= cap) break;
+        // groups of 64 candidates in this round: all four while many survivors are still wanted, fewer near the cap (1.5
+        // candidates per wanted survivor), so that the last round does not pay 256^2/2 pair tests for a handful of boxes
+        int G = ((cap - nk0) * 3 / 2 + 63) >> 6;
+        G = G > 4 ? 4 : G;
         const int pos = c0 + tid;
-        const bool valid = pos < n;
+        const bool valid = pos < n && wave < G;
         Box me = {0.f, 0.f, 0.f, 0.f, 1.f};
         if (valid) get(pos, me);
-        const bool alive = valid && !suppressed_by(kept, 0, nk0, me, r);
+        const bool alive = valid && !suppressed_by(kept, 0, nk0, me, r);     // the long scan, spread over the waves
         alive_s[tid] = alive ? 1 : 0;
+        rb[tid] = me;
         __syncthreads();
-        if (wave == 0) {
-            int nk = nk0;
-            for (int sub = 0; sub < 4 && nk < cap && c0 + sub * 64 < n; ++sub) {
-                const int p2 = c0 + sub * 64 + lane;
-                Box b2 = me;
-                bool al = alive;
-                if (sub > 0) {
-                    al = p2 < n && alive_s[sub * 64 + lane];
-                    if (__ballot(al) == 0ull) continue;
-                    b2 = Box{0.f, 0.f, 0.f, 0.f, 1.f};
-                    if (al) get(p2, b2);
-                }
-                al = al && !suppressed_by(kept, nk0, nk, b2, r);          // boxes kept earlier in this round
-                const unsigned long long km = settle64(b2, al, r);
-                const bool keepme = (km >> lane) & 1ull;
-                const int slot = nk + __popcll(km & ((1ull << lane) - 1ull));
-                if (keepme && slot < cap) {
-                    kept.set(slot, b2);
-                    emit(slot, p2);
-                }
-                nk += __popcll(km);
-                __threadfence_block();
-                __builtin_amdgcn_wave_barrier();
+        // Pairwise bits inside the round, all 256 threads at once: bit i of sup[t] = candidate 64 t + i comes before me
+        // in the order, survived the long scan and overlaps me.  (Only a candidate that is alive can ever suppress.)
+        unsigned long long sup[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t > wave || wave >= G) break;              // (wave-uniform)
+            // group t's boxes: one per lane, handed round through v_readlane (no LDS round trip per pair)
+            const Box g = rb[t * 64 + lane];
+            const unsigned long long gmask = __ballot(alive_s[t * 64 + lane] != 0);
+            const int before = t < wave ? 64 : lane;                         // group members that precede me
+            unsigned long long bits = 0ull;
+            for (unsigned long long m = gmask; m; m &= m - 1ull) {
+                const int i = __builtin_ctzll(m);
+                const Box o = box_of_lane(g, i);
+                if (alive && i < before && suppresses(o, me, r)) bits |= 1ull << i;
             }
-            if (lane == 0) *nk_s = nk;
+            sup[t] = bits;
         }
-        __syncthreads();
+        // The greedy decisions, one 64-candidate group after the other (group t on wave t): a candidate is kept iff none
+        // of the candidates KEPT before it in this round overlaps it.  kmw[2t], kmw[2t+1] = keep mask of group t.
+        for (int t = 0; t < G; ++t) {
+            if (wave == t) {
+                int nk = *nk_s;
+                unsigned long long km = 0ull;
+                if (nk < cap && c0 + t * 64 < n) {
+                    bool al = alive;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < t) al = al && (sup[u] & (((unsigned long long)kmw[2 * u + 1] << 32) | kmw[2 * u])) == 0ull;
+                    const unsigned long long mine = sup[t];
+                    for (unsigned long long m = __ballot(al); m; m &= m - 1ull) {
+                        const int i = __builtin_ctzll(m);
+                        const unsigned lo = __builtin_amdgcn_readlane((unsigned)mine, i);
+                        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mine >> 32), i);
+                        if (((((unsigned long long)hi << 32) | lo) & km) == 0ull) km |= 1ull << i;
+                    }
+                    const bool keepme = (km >> lane) & 1ull;
+                    const int slot = nk + __popcll(km & ((1ull << lane) - 1ull));
+                    if (keepme && slot < cap) {
+                        kept.set(slot, me);
+                        emit(slot, pos);
+                    }
+                    nk += __popcll(km);
+                }
+                if (lane == 0) {
+                    kmw[2 * t] = (unsigned)km;
+                    kmw[2 * t + 1] = (unsigned)(km >> 32);
+                    *nk_s = nk;
+                }
+            }
+            __syncthreads();
+        }
+        c0 += G * 64;
     }
     const int nk = *nk_s;
     return nk < cap ? nk : cap;
@@ -364,7 +397,7 @@ __device__ __forceinline__ float key_score(unsigned k)
 // Shared by both Detect kernels: sort the n keys in sk[] and continue the greedy NMS with them; survivors
 // are packed as [score, x1, y1, x2, y2] rows (normalised boxes, detection.py:59-62) as they are kept.
 __device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int top_k, const NmsRule &r, const KeepList &kept,
-                                            unsigned char *alive_s, int *nk_s, const float *__restrict__ sb,
+                                            unsigned char *alive_s, int *nk_s, Box *rb, unsigned *kmw, const float *__restrict__ sb,
                                             const float *__restrict__ nb, float *__restrict__ orow, long long *stamps)
 {
     (void)stamps;
@@ -375,7 +408,7 @@ __device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int t
     bitonic_sort_desc(sk, N, threadIdx.x, 256);
     DT_STAMP(stamps, 4);
     return block_greedy_nms(
-        n, top_k, r, kept, alive_s, nk_s,
+        n, top_k, r, kept, alive_s, nk_s, rb, kmw,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
             const f32x4 v = *(const f32x4 *)(sb + (size_t)p * 4);
@@ -392,7 +425,7 @@ __device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int t
         });
 }
 
-// LDS layout: sk[kcap] | kept (20 B x top_k) | ctl[16] | alive[256 B] | wsum[8] | hist[256] | (LDS keys: sc[P])
+// LDS layout: sk[kcap] | kept (20 B x top_k) | ctl[16] | alive[256 B] | wsum[8] | hist[256] | round boxes (20 B x 256) | keep masks[8] | (LDS keys: sc[P])
 __device__ __forceinline__ void detect_lds(unsigned long long *dsm, int kcap, int top_k, unsigned long long *&sk, void *&kept,
                                            int *&ctl, unsigned char *&alive_s, int *&wsum, unsigned *&extra)
 {
@@ -403,7 +436,8 @@ __device__ __forceinline__ void detect_lds(unsigned long long *dsm, int kcap, in
     wsum = (int *)(alive_s + 256);
     extra = (unsigned *)(wsum + 8);
 }
-static size_t detect_lds_bytes(int kcap, int top_k) { return (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 64 + 256 + 32 + 256 * 4; }
+constexpr int kRoundWords = 256 * (int)sizeof(Box) / 4 + 8;      // the NMS round's boxes and keep masks, in 4-byte words
+static size_t detect_lds_bytes(int kcap, int top_k) { return (size_t)kcap * 8 + (size_t)top_k * sizeof(Box) + 64 + 256 + 32 + 256 * 4 + kRoundWords * 4; }
 
 // The workgroup turns its class row (score > conf_thresh, detection.py:53) into score keys.  Greedy NMS walks
 // candidates in descending score (cpu_nms.pyx:31) and Detect stops at top_k survivors (detection.py:63), so the
@@ -432,7 +466,9 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
     const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // seg = b*C + cl
     const int cl = seg % C, b = seg / C;
     float *row = scoresT + (size_t)seg * P;
-    unsigned *sc = GK ? (unsigned *)row : hist + 256;
+    Box *rb = (Box *)(hist + 256);
+    unsigned *kmw = hist + 256 + kRoundWords - 8;
+    unsigned *sc = GK ? (unsigned *)row : hist + 256 + kRoundWords;
     float *orow = out + (size_t)seg * top_k * 5;
     if (cl == 0) {                                                         // background: detection.py:51 skips it
         for (int i = tid; i < top_k * 5; i += 256) orow[i] = 0.f;
@@ -572,7 +608,7 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
         }
         __syncthreads();
         DT_STAMP(stamps, 3);
-        nk = sort_and_nms(sk, nsel, top_k, rule, kept, alive_s, ctl + 1, sb, nb, orow, stamps);
+        nk = sort_and_nms(sk, nsel, top_k, rule, kept, alive_s, ctl + 1, rb, kmw, sb, nb, orow, stamps);
         DT_STAMP(stamps, 5);
         taken += nsel;
         if (nk >= top_k || taken >= n) break;
