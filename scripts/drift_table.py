@@ -11,6 +11,8 @@ Writes
 The numbers justify the headline dtype choice and set tests/test_gpu_net.py:DRIFT_BOUNDS (<= 1.5x measured).
 """
 import argparse
+import os
+os.environ.setdefault("TDRN_FUSE_FIRST", "0")     # keep the first conv's output tensor (16-bit modes fuse it away) for the stage table
 import csv
 import importlib
 import os

@@ -55,6 +55,10 @@ struct PatchParams {
     int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
     int M;                         // B*H*W
     int max_wgs;                   // > 0: cap on the persistent grid
+    // FUSE instantiation only: the layer's input is the first conv's output (3 -> 64 channels, 3x3, pad 1, stride 1, BN folded,
+    // ReLU), computed here from the raw frames instead of being read back from HBM
+    const float *fx, *fw, *fb;     // frames NCHW fp32 [B][3][S][S]; first-conv weights [64][27] (k = c*9 + r*3 + q) and bias [64], fp32
+    int fS, fCout;                 // frame size (= H = W of this layer) and the first conv's real channel count
     int ablate;                    // diagnostics (TDRN_CONV_ABLATE): 1 = loaders issue nothing, 2 = consumers skip ds_read+MFMA
 #ifdef TDRN_PATCH_STAMP
     unsigned *stamps;              // diagnostics build only: [workgroup][wave][8] cycle sums (s_memtime), see the launcher
@@ -133,9 +137,13 @@ constexpr int kSlotsPerLoader = (kPatchSlots + 3) / 4;
 
 // TW = 32 / 16: 2-D tiles of (256/TW) x TW pixels of one image; TW = 0: flat tiles.  Compile-time: with a runtime
 // tile width every per-element step of the pooled epilogue carried a branch and the index math its shifts as variables.
-template <typename DT, int BN, int TW>
+// FUSE (16-bit types, BN = 64, TW = 32, one cout tile): the loader waves COMPUTE the patch of the next item -- the first conv
+// (layers.hip, first_conv_mfma_kernel: same operand layout, same instruction, bit-identical values) on the raw frame's
+// 12 x 36 halo tile -- instead of reading the first conv's 420-MB output back: that tensor never exists.
+template <typename DT, int BN, int TW, bool FUSE = false>
 __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 {
+    static_assert(!FUSE || (BN == 64 && TW == 32 && sizeof(DT) == 2), "fused first conv: 16-bit, 64 couts, 8x32 tiles");
     constexpr bool FLAT = TW == 0;
     constexpr int LGTW = TW == 32 ? 5 : 4;              // (2-D tiles only)
     constexpr int TH = TW ? 256 / TW : 0;
@@ -152,7 +160,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     constexpr int OFF_W = 2 * kPatchBytes;
     constexpr int OFF_S = OFF_W + RING * WBYTES;
     constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the next item (one 1-KiB LDS-DMA piece)
-    constexpr int LDS = OFF_B + 1024;
+    constexpr int RAWN = 3 * 12 * 36;                   // FUSE: fp32 halo tile of the frame (3 planes x 12 rows x 36 columns)
+    constexpr int RAWB = ((RAWN + 63) / 64) * 256;      // ... in whole 256-byte LDS-DMA pieces
+    constexpr int OFF_R = OFF_B + 1024;                 // two raw tiles + the first conv's bias
+    constexpr int LDS = FUSE ? OFF_R + 2 * RAWB + 256 : OFF_B + 1024;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
 
@@ -195,6 +206,115 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 }
             }
         }
+        // ---- FUSE: raw-tile loads and the first conv on the matrix cores ----------------------------------------------
+        const int f_r32 = lane & 31, f_hh = lane >> 5;
+        [[maybe_unused]] int r_rq[6], r_off[6];         // my elements of a raw tile: (row << 16 | col) or -1, offset in the frame
+        [[maybe_unused]] int koff1[16];                 // LDS offset of my k = (c, dy, dx), relative to a pixel's halo origin
+        [[maybe_unused]] u32x4 wq1[2][2];               // packed first-conv weights [cout tile][k step]
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int i = (lw + 4 * j) * 64 + lane;
+                const int c = i / (12 * 36), rem = i - c * (12 * 36);
+                const int r = rem / 36, q = rem - r * 36;
+                r_rq[j] = i < RAWN ? ((r << 16) | q) : -1;
+                r_off[j] = (c * p.fS + r) * p.fS + q;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = 16 * (s2 >> 3) + 8 * f_hh + (s2 & 7);
+                const int c = k / 9, r = (k - 9 * c) / 3, q = k - 9 * c - 3 * r;
+                koff1[s2] = k < 27 ? (c * 12 + r) * 36 + q : 0;      // k >= 27 pads K: its weight is 0
+            }
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int co = ci * 32 + f_r32, k0 = 16 * ks + 8 * f_hh + 2 * jj;
+                        const float a = (k0 < 27 && co < p.fCout) ? p.fw[co * 27 + k0] : 0.f;
+                        const float b2 = (k0 + 1 < 27 && co < p.fCout) ? p.fw[co * 27 + k0 + 1] : 0.f;
+                        wq1[ci][ks][jj] = pack2<DT>(a, b2);
+                    }
+            if (lw == 0) ((float *)(smem + OFF_R + 2 * RAWB))[lane] = lane < p.fCout ? p.fb[lane] : 0.f;
+        }
+        auto tile_origin = [&](int item, int &b, int &y0, int &x0) {
+            const int mt = item / p.n_tiles;
+            b = mt / p.tiles_per_img;
+            const int tt = mt - b * p.tiles_per_img, ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+            y0 = ty * TH; x0 = tx * TW;
+        };
+        auto load_raw = [&](int item, int buf) -> int {      // my pieces of the item's raw halo tile; returns how many were issued
+            int n = 0;
+            if constexpr (FUSE) {
+                int b, y0, x0;
+                tile_origin(item, b, y0, x0);
+                const int iy0 = y0 - 2, ix0 = x0 - 2;
+                const float *xb = p.fx + (size_t)b * 3 * p.fS * p.fS + ((long long)iy0 * p.fS + ix0);
+                char *dst = smem + OFF_R + buf * RAWB;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if ((lw + 4 * j) * 64 >= RAWN) continue;                       // (wave-uniform)
+                    const int yy = iy0 + (r_rq[j] >> 16), xx = ix0 + (r_rq[j] & 0xffff);
+                    const bool ok = r_rq[j] >= 0 && (unsigned)yy < (unsigned)p.fS && (unsigned)xx < (unsigned)p.fS;
+                    const char *src = ok ? (const char *)(xb + r_off[j]) : p.zero + (lane & 15) * 4;
+                    if constexpr (!(TDRN_PATCH_ABLATE & 1))
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)(dst + (lw + 4 * j) * 256), 4, 0, 0);
+                    ++n;
+                }
+            }
+            return n;
+        };
+        // 32 patch pixels (flat index tt*32 + lane%32 over the (TH+2) x (TW+2) patch) x 64 channels -> patch buffer rows
+        auto first_conv_tile = [&](int item, int tt, int rawb, char *dstbuf) {
+            if constexpr (FUSE) {
+                int b, y0, x0;
+                tile_origin(item, b, y0, x0);
+                const int pq = tt * 32 + f_r32;
+                const bool valid = pq < (TH + 2) * RS;
+                const int py = pq / RS, px = pq - py * RS;
+                // outside the frame the NEXT conv pads with zeros (not with the first conv evaluated out there)
+                const bool inimg = valid && (unsigned)(y0 - 1 + py) < (unsigned)p.fS && (unsigned)(x0 - 1 + px) < (unsigned)p.fS;
+                const float *raw = (const float *)(smem + OFF_R + rawb * RAWB);
+                const float *b1 = (const float *)(smem + OFF_R + 2 * RAWB);
+                const int porg = valid ? py * 36 + px : 0;
+                float xv[16];
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) xv[s2] = raw[porg + koff1[s2]];
+                f32x16 a1[2];
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *(const f32x4 *)(b1 + ci * 32 + 8 * g + 4 * f_hh);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a1[ci][4 * g + j] = bv[j];
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 xq;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xq[jj] = pack2<DT>(xv[8 * ks + 2 * jj], xv[8 * ks + 2 * jj + 1]);
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci) MmaP<DT>::run(wq1[ci][ks], xq, a1[ci]);
+                }
+                if (valid) {
+                    char *row = dstbuf + pq * 128 + 8 * f_hh;
+                    const int sw = (pq >> 1) & 7;
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float q4[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) q4[j] = inimg ? fmaxf(a1[ci][4 * g + j], 0.f) : 0.f;
+                            *(uint2 *)(row + (((4 * ci + g) ^ sw) << 4)) = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
+                        }
+                }
+            }
+        };
         int table_mt = -1;
         auto patch_table = [&](int item) {              // per pixel tile: where my patch rows live
             const int mt = item / p.n_tiles;
@@ -268,11 +388,25 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
         };
 
+        if constexpr (FUSE) {
+            if (n_it > 0) {
+                load_raw(item0, 0);
+                if (n_it > 1) load_raw(item0 + istride, 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // every loader wave's share of the raw tiles (and the bias) is in LDS
+            if (n_it > 0)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (lw + 4 * q < ((TH + 2) * RS + 31) / 32) first_conv_tile(item0, lw + 4 * q, 0, smem);
+        }
         if (n_it > 0) {
             weight_item();
-            patch_table(item0);
+            if constexpr (!FUSE) {
+                patch_table(item0);
 #pragma unroll
-            for (int j = 0; j < kSlotsPerLoader; ++j) load_patch(j, 0u, smem);
+                for (int j = 0; j < kSlotsPerLoader; ++j) load_patch(j, 0u, smem);
+            }
 #pragma unroll
             for (int k = 0; k < RING - 1; ++k)
                 if (k < n_steps) load_weights();
@@ -280,7 +414,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             if (lw == 0 && live)
                 glds(lane < BN / 4 ? (const char *)(p.bias + (item0 % p.n_tiles) * BN) + lane * 16 : p.zero, smem + OFF_B);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
         int tap = 0, c_it = 0, c_cc = 0, carried = 0;
@@ -295,7 +429,19 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 load_weights();
                 issued = WL;
             }
-            if (p_it < n_it && tap < 6) {
+            if constexpr (FUSE) {
+                // tap 0: the raw tile of the item after next; taps 1-3: one 32-pixel slice each of the NEXT item's patch
+                // (its raw tile arrived an item ago)
+                if (tap == 0 && p_it + 1 < n_it) issued += load_raw(item0 + (p_it + 1) * istride, (p_it + 1) & 1);
+                if (tap >= 1 && tap <= 3 && p_it < n_it && lw + 4 * (tap - 1) < ((TH + 2) * RS + 31) / 32) {
+                    // (this is bulk work with an item's worth of slack: it must not pre-empt the consumers' MFMA issue the way
+                    // the few DMA instructions of a step are meant to)
+                    if (TDRN_PATCH_PRIO >= 4) __builtin_amdgcn_s_setprio(0);
+                    first_conv_tile(item0 + p_it * istride, lw + 4 * (tap - 1), p_it & 1, smem + pbuf * kPatchBytes);
+                    if (TDRN_PATCH_PRIO == 4) __builtin_amdgcn_s_setprio(2);
+                    if (TDRN_PATCH_PRIO == 5) __builtin_amdgcn_s_setprio(3);
+                }
+            } else if (p_it < n_it && tap < 6) {
                 char *dstbuf = smem + pbuf * kPatchBytes;
                 const unsigned ccoff = (unsigned)(p_cc * 128);
                 switch (tap) {
@@ -319,6 +465,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             // ring of 3: everything issued before this step has landed; ring of 4: before the previous step
             STAMP(0);                                       // issue
             wait_vmcnt(live ? issued + (RING == 4 ? carried : 0) : 0);
+            if constexpr (FUSE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my patch rows are written
             STAMP(1);                                       // landing of the previous step's pieces
             carried = issued;
             __builtin_amdgcn_s_barrier();
@@ -547,6 +694,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
     };
 
+    if constexpr (FUSE) __builtin_amdgcn_s_barrier();   // (the loaders' raw tiles)
     __builtin_amdgcn_s_barrier();                       // prologue operands landed
     if (TDRN_PATCH_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // static: the younger half
     if (TDRN_PATCH_PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // static: all consumers over the loaders
@@ -643,6 +791,14 @@ template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p,
     // a multiple of 8 workgroups (the item split is per XCD); surplus workgroups find no item and exit
     int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
     if (p.max_wgs > 0 && grid > p.max_wgs) grid = p.max_wgs;
+    if constexpr (BN == 64 && sizeof(DT) == 2) {
+        if (p.fx) {
+            if (p.tw != 32 || p.n_tiles != 1) return TDRN_E_UNSUPPORTED;
+            hipLaunchKernelGGL((conv3x3_patch_kernel<DT, 64, 32, true>), dim3(grid), dim3(768), 0, s, p);
+            return hip_status(hipGetLastError());
+        }
+    }
+    if (p.fx) return TDRN_E_UNSUPPORTED;
     if (p.tw == 0) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 0>), dim3(grid), dim3(768), 0, s, p);
     else if (p.tw == 32) hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 32>), dim3(grid), dim3(768), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<DT, BN, 16>), dim3(grid), dim3(768), 0, s, p);
@@ -682,6 +838,7 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
+    p.fx = a.fuse_x; p.fw = a.fuse_w; p.fb = a.fuse_b; p.fS = a.H; p.fCout = a.fuse_cout;
     p.max_wgs = a.max_wgs > 0 ? (a.max_wgs / 8) * 8 : 0;
     if (p.items <= 0) return TDRN_OK;
 #ifdef TDRN_PATCH_STAMP

@@ -549,6 +549,7 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     // what else is in the batch)
     if (p.splits == 1 && use_patch && patch_conv_supported(a) && a.H * a.W >= use_patch * 400)
         return launch_conv3x3_patch(a, nullptr, s);
+    if (a.fuse_x) return TDRN_E_UNSUPPORTED;             // only the patch kernel computes the first conv itself
     int rc = TDRN_E_ARG;
     switch (a.dtype) {
         case TDRN_F32: rc = launch_dt<float>(p, a.phases, s); break;

@@ -36,6 +36,9 @@ struct ConvArgs {
     void *partial = nullptr;        // fp32 scratch of conv_splitk_bytes()
     long long o_bs = 0, o_rs = 0, o_cs = 0, o_base = 0, o_pr = 0, o_pc = 0;
     int dtype = TDRN_BF16;
+    // patch kernel, first conv fused in (conv3x3_patch.hip FUSE): frames NCHW fp32, the first conv's folded weights [c][27] and bias
+    const float *fuse_x = nullptr, *fuse_w = nullptr, *fuse_b = nullptr;
+    int fuse_cout = 0;
     int max_wgs = 0;                // patch kernel: > 0 caps the persistent grid (a multiple of 8), leaving CUs to concurrent lanes
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);

@@ -95,6 +95,7 @@ struct tdrn_net {
     // 0.24 ms; held back, they run beside conv6/conv7 and the small top-down layers instead (+1.4 % frames/s; held until fc7
     // or capped to 128..224 workgroups: no further gain).  TDRN_LATE_SIDE 0: off, 2: until fc7; TDRN_SIDE_GRID: the cap.
     int t_late = -1, t_late2 = -1;
+    int fuse_first = -1;                 // index of the conv whose patch loader computes the first conv itself (16-bit modes), or -1
     int late_side = 1, side_grid = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
@@ -602,6 +603,27 @@ struct tdrn_net {
                 ops.insert(ops.begin() + (long)prod + 1, o);
             }
         }
+        // first conv fused into the loader of the conv behind it (conv3x3_patch.hip FUSE): 16-bit modes, stride 1, 64 channels,
+        // 8x32 tiles, and nobody else reads the first conv's output (TDRN_FUSE_FIRST=0 keeps the two launches)
+        {
+            const char *fe = getenv("TDRN_FUSE_FIRST");
+            fuse_first = -1;
+            if (!(fe && atoi(fe) == 0) && cfg.dtype != TDRN_F32 && conv_patch_enabled() && ops.size() > 1 && ops[0].kind == OP_FIRST &&
+                ops[1].kind == OP_CONV && ops[0].stride == 1 && tensors[ops[0].out].Cpad == 64) {
+                const Op &c = ops[1];
+                const Tensor &ti = tensors[ops[0].out];
+                int readers = 0;
+                for (const Op &o : ops) readers += (o.in == ops[0].out) + (o.res == ops[0].out);
+                if (c.in == ops[0].out && readers == 1 && c.k == 3 && c.stride == 1 && c.pad == 1 && c.dil == 1 && c.phases == 1 && c.res < 0 &&
+                    c.out_kind == OUT_TENSOR && c.Npad == 64 && c.Cin == 64 && ti.W % 32 == 0 && ti.H % 8 == 0 && ti.H == ti.W && c.lane == 0)
+                    fuse_first = 1;
+                if (fuse_first >= 0) {                   // the fused launch carries both layers' algorithmic work
+                    ops[1].flops += ops[0].flops;
+                    ops[1].bytes += 3.0 * ops[0].hw * ops[0].hw * 4 - (double)ti.H * ti.W * ti.Cpad * es;
+                    ops[0].flops = 0; ops[0].bytes = 0;
+                }
+            }
+        }
         if (const char *e = getenv("TDRN_LATE_SIDE")) late_side = atoi(e);
         if (const char *e = getenv("TDRN_SIDE_GRID")) side_grid = atoi(e);
         if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 32;
@@ -924,6 +946,7 @@ struct tdrn_net {
             bool skip = false;
             if (o.kind == OP_OFF_OUT && !io->offsets[o.scale]) skip = true;
             if (o.kind == OP_LOC_OUT && !io->loc_maps[o.scale]) skip = true;
+            if (o.kind == OP_FIRST && fuse_first >= 0) skip = true;            // computed inside the next conv's patch loader
             if (skip) continue;
             const int lane = lanes ? o.lane : 0;
             hipStream_t s = lane == 0 ? s0 : side[lane - 1];
@@ -955,6 +978,10 @@ struct tdrn_net {
                     a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                     a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
                     if (lane != 0) a.max_wgs = side_grid;
+                    if ((int)oi == fuse_first) {
+                        a.fuse_x = io->x; a.fuse_w = (const float *)(wb + ops[0].w_off); a.fuse_b = (const float *)(wb + ops[0].b_off);
+                        a.fuse_cout = ops[0].Cout;
+                    }
                     if (o.out_kind == OUT_TENSOR) {
                         const Tensor &to = tensors[o.out];
                         a.out = tptr(ws, o.out, B);
