@@ -33,12 +33,12 @@ def short(name):
 
 
 def forwards(rows):
-    """split the dispatches (enqueue order) into forwards: each starts at a first_conv kernel"""
+    """split the dispatches (enqueue order) into forwards: each starts at the first-conv kernel (or the conv it is fused into)"""
     rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
     out, cur = [], None
     for r in rows:
         n = short(r["Kernel_Name"])
-        if n.startswith("first_conv"):
+        if n.startswith("first_conv") or (n.startswith("conv3x3_patch_kernel") and n.rstrip().endswith("true>")):     # (16-bit plans: the first conv lives in conv1_2's loader)
             cur = []
             out.append(cur)
         if cur is not None and "tdrn" in r["Kernel_Name"]:
