@@ -569,3 +569,42 @@ def test_hipgraph_replay_equals_eager():
         torch.cuda.synchronize()
         for got, want in zip(out, e):
             assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("model,args", [("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True)), ("ssd4scale_vgg", (320, 21, 1024, False, False))])
+def test_fused_first_conv_equals_two_launches(model, args, monkeypatch):
+    """16-bit plans compute the first conv inside conv1_2's patch loader (conv3x3_patch.hip FUSE): same operand layout and
+    instruction as the stand-alone kernel, so every output is BIT-identical to the two-launch plan (TDRN_FUSE_FIRST=0) --
+    at the build size, at other frame sizes (tiles at every border, fewer items than CUs) and at batch 1 / 3 / 8."""
+    # (the multihead DRN needs a >= 5x5 coarsest map for its 5x5 deformable heads: sizes from 320 up)
+    cases = [(320, 3), (320, 8), (384, 3), (448, 1), (704, 1)] + ([(192, 3), (256, 1)] if model == "ssd4scale_vgg" else [])
+    for dtype in ("bf16", "fp16"):
+        monkeypatch.setenv("TDRN_FUSE_FIRST", "1")
+        fused, _ = _build(model, args)
+        fused.set_compute_dtype(dtype)
+        monkeypatch.setenv("TDRN_FUSE_FIRST", "0")
+        plain, _ = _build(model, args)
+        plain.set_compute_dtype(dtype)
+        for size, batch in cases:
+            x = torch.from_numpy(synth.synth_frames(batch, size, seed=70 + size + batch)).to(DEV)
+            monkeypatch.setenv("TDRN_FUSE_FIRST", "1")
+            a = fused(x)
+            monkeypatch.setenv("TDRN_FUSE_FIRST", "0")
+            b = plain(x)
+            for u, v in zip(a, b):
+                if torch.is_tensor(u):
+                    assert torch.equal(u, v), (model, dtype, size, batch)
+                else:
+                    for uu, vv in zip(u, v):
+                        assert torch.equal(uu, vv), (model, dtype, size, batch)
+        # (not vacuous: the two plans do differ)
+        names = []
+        for net in (fused, plain):
+            eng = net._engine
+            eng.set_profile(1)
+            xs = torch.from_numpy(synth.synth_frames(1, 320, seed=3)).to(DEV)
+            eng.forward(xs)
+            torch.cuda.synchronize()
+            names.append([o["name"].split(":")[0] for o in eng.op_stats()])
+            eng.set_profile(0)
+        assert "first_conv" not in names[0] and names[1][0] == "first_conv"
