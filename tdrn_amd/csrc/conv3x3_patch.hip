@@ -268,10 +268,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             return n;
         };
         // 32 patch pixels (flat index tt*32 + lane%32 over the (TH+2) x (TW+2) patch) x 64 channels -> patch buffer rows
-        auto first_conv_tile = [&](int item, int tt, int rawb, char *dstbuf) {
+        [[maybe_unused]] int f_y0 = 0, f_x0 = 0;          // tile origin of the item whose patch is being computed (set once per item)
+        auto first_conv_tile = [&](int tt, int rawb, char *dstbuf) {
             if constexpr (FUSE) {
-                int b, y0, x0;
-                tile_origin(item, b, y0, x0);
+                const int y0 = f_y0, x0 = f_x0;
                 const int pq = tt * 32 + f_r32;
                 const bool valid = pq < (TH + 2) * RS;
                 const int py = pq / RS, px = pq - py * RS;
@@ -395,10 +395,13 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();               // every loader wave's share of the raw tiles (and the bias) is in LDS
-            if (n_it > 0)
+            if (n_it > 0) {
+                int b_;
+                tile_origin(item0, b_, f_y0, f_x0);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    if (lw + 4 * q < ((TH + 2) * RS + 31) / 32) first_conv_tile(item0, lw + 4 * q, 0, smem);
+                    if (lw + 4 * q < ((TH + 2) * RS + 31) / 32) first_conv_tile(lw + 4 * q, 0, smem);
+            }
         }
         if (n_it > 0) {
             weight_item();
@@ -432,12 +435,18 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             if constexpr (FUSE) {
                 // tap 0: the raw tile of the item after next; taps 1-3: one 32-pixel slice each of the NEXT item's patch
                 // (its raw tile arrived an item ago)
-                if (tap == 0 && p_it + 1 < n_it) issued += load_raw(item0 + (p_it + 1) * istride, (p_it + 1) & 1);
+                if (tap == 0) {
+                    if (p_it + 1 < n_it) issued += load_raw(item0 + (p_it + 1) * istride, (p_it + 1) & 1);
+                    if (p_it < n_it) {
+                        int b_;
+                        tile_origin(item0 + p_it * istride, b_, f_y0, f_x0);
+                    }
+                }
                 if (tap >= 1 && tap <= 3 && p_it < n_it && lw + 4 * (tap - 1) < ((TH + 2) * RS + 31) / 32) {
                     // (this is bulk work with an item's worth of slack: it must not pre-empt the consumers' MFMA issue the way
                     // the few DMA instructions of a step are meant to)
                     if (TDRN_PATCH_PRIO >= 4) __builtin_amdgcn_s_setprio(0);
-                    first_conv_tile(item0 + p_it * istride, lw + 4 * (tap - 1), p_it & 1, smem + pbuf * kPatchBytes);
+                    first_conv_tile(lw + 4 * (tap - 1), p_it & 1, smem + pbuf * kPatchBytes);
                     if (TDRN_PATCH_PRIO == 4) __builtin_amdgcn_s_setprio(2);
                     if (TDRN_PATCH_PRIO == 5) __builtin_amdgcn_s_setprio(3);
                 }
