@@ -130,7 +130,6 @@ __device__ __forceinline__ void wait_vmcnt(int n)   // n is wave-uniform
 #endif
 constexpr int kRing = TDRN_PATCH_RING;          // weight ring depth for the 128-cout kernels: weights go kRing-1 steps ahead
 constexpr int kPatchSlots = kRing == 4 ? 43 : 44;   // 8-row LDS-DMA pieces per patch buffer (344 / 352 rows)
-constexpr int kPatchBytes = kPatchSlots * 1024;
 constexpr int kSlotsPerLoader = (kPatchSlots + 3) / 4;
 
 }  // namespace
@@ -146,21 +145,30 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     static_assert(!FUSE || (BN == 64 && TW == 32 && sizeof(DT) == 2), "fused first conv: 16-bit, 64 couts, 8x32 tiles");
     constexpr bool FLAT = TW == 0;
     constexpr int LGTW = TW == 32 ? 5 : 4;              // (2-D tiles only)
-    constexpr int TH = TW ? 256 / TW : 0;
+    constexpr int TPX = FUSE ? 512 : 256;               // pixels per work item (FUSE: 16 x 32, see below)
+    constexpr int TH = TW ? TPX / TW : 0;
+    constexpr int PXG = TPX / 64;                       // pixel groups of 64 (one per consumer wave and cout group)
+    constexpr int CG = 8 / PXG;                         // cout groups
     constexpr int ES = elem_traits<DT>::bytes;
     constexpr int P16 = elem_traits<DT>::per16;
     constexpr int CK = 128 / ES;
-    constexpr int BNH = BN / 2;                         // couts per consumer wave (8 consumers = 4 pixel groups x 2 cout halves)
+    constexpr int BNH = BN / CG;                        // couts per consumer wave (8 consumers = PXG pixel groups x CG cout groups)
     constexpr int WC = BNH / 32;                        // cout tiles per consumer
     constexpr int WBYTES = BN * 128;                    // one weight slot
     constexpr int WL = BN / 32;                         // weight LDS-DMA pieces per loader wave per step
     constexpr int RING = BN == 128 ? kRing : 3;         // (the 64-cout kernels have LDS to spare but gain nothing)
     constexpr int SROWS = (ES == 2 ? 16 : 8) / ((RING == 4 && BN == 128) ? 2 : 1);   // pixels per epilogue round (per wave)
     constexpr int SSTRIDE = BNH * ES + 16;              // staging row stride (bytes)
-    constexpr int OFF_W = 2 * kPatchBytes;
+    constexpr int NPB = FUSE ? 1 : 2;                   // patch buffers (FUSE: one; the next patch is computed under the epilogue)
+    constexpr int PSLOTS = FUSE ? ((TH + 2) * (TW + 2) + 7) / 8 : kPatchSlots;   // 8-row pieces per patch buffer
+    constexpr int PBYTES = PSLOTS * 1024;
+    constexpr int OFF_W = NPB * PBYTES;
     constexpr int OFF_S = OFF_W + RING * WBYTES;
     constexpr int OFF_B = OFF_S + 8 * SROWS * SSTRIDE;  // bias of the next item (one 1-KiB LDS-DMA piece)
-    constexpr int RAWN = 3 * 12 * 36;                   // FUSE: fp32 halo tile of the frame (3 planes x 12 rows x 36 columns)
+    constexpr int RAWR = TH + 4, RAWC = 36;             // FUSE: fp32 halo tile of the frame: 3 planes x (TH + 4) rows x (TW + 4) columns
+    constexpr int RAWN = 3 * RAWR * RAWC;
+    constexpr int RAWP = (RAWN + 63) / 64, RAWJ = (RAWP + 3) / 4;      // 256-byte LDS-DMA pieces, and pieces per loader wave
+    constexpr int FTILES = ((TH + 2) * (TW + 2) + 31) / 32, FTJ = (FTILES + 3) / 4;   // 32-pixel slices of the patch, per loader wave
     constexpr int RAWB = ((RAWN + 63) / 64) * 256;      // ... in whole 256-byte LDS-DMA pieces
     constexpr int OFF_R = OFF_B + 1024;                 // two raw tiles + the first conv's bias
     constexpr int LDS = FUSE ? OFF_R + 2 * RAWB + 256 : OFF_B + 1024;
@@ -208,15 +216,15 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         }
         // ---- FUSE: raw-tile loads and the first conv on the matrix cores ----------------------------------------------
         const int f_r32 = lane & 31, f_hh = lane >> 5;
-        [[maybe_unused]] int r_rq[6], r_off[6];         // my elements of a raw tile: (row << 16 | col) or -1, offset in the frame
+        [[maybe_unused]] int r_rq[FUSE ? RAWJ : 1], r_off[FUSE ? RAWJ : 1];         // my elements of a raw tile: (row << 16 | col) or -1, offset in the frame
         [[maybe_unused]] int koff1[16];                 // LDS offset of my k = (c, dy, dx), relative to a pixel's halo origin
         [[maybe_unused]] u32x4 wq1[2][2];               // packed first-conv weights [cout tile][k step]
         if constexpr (FUSE) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < RAWJ; ++j) {
                 const int i = (lw + 4 * j) * 64 + lane;
-                const int c = i / (12 * 36), rem = i - c * (12 * 36);
-                const int r = rem / 36, q = rem - r * 36;
+                const int c = i / (RAWR * RAWC), rem = i - c * (RAWR * RAWC);
+                const int r = rem / RAWC, q = rem - r * RAWC;
                 r_rq[j] = i < RAWN ? ((r << 16) | q) : -1;
                 r_off[j] = (c * p.fS + r) * p.fS + q;
             }
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             for (int s2 = 0; s2 < 16; ++s2) {
                 const int k = 16 * (s2 >> 3) + 8 * f_hh + (s2 & 7);
                 const int c = k / 9, r = (k - 9 * c) / 3, q = k - 9 * c - 3 * r;
-                koff1[s2] = k < 27 ? (c * 12 + r) * 36 + q : 0;      // k >= 27 pads K: its weight is 0
+                koff1[s2] = k < 27 ? (c * RAWR + r) * RAWC + q : 0;      // k >= 27 pads K: its weight is 0
             }
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 const float *xb = p.fx + (size_t)b * 3 * p.fS * p.fS + ((long long)iy0 * p.fS + ix0);
                 char *dst = smem + OFF_R + buf * RAWB;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
+                for (int j = 0; j < RAWJ; ++j) {
                     if ((lw + 4 * j) * 64 >= RAWN) continue;                       // (wave-uniform)
                     const int yy = iy0 + (r_rq[j] >> 16), xx = ix0 + (r_rq[j] & 0xffff);
                     const bool ok = r_rq[j] >= 0 && (unsigned)yy < (unsigned)p.fS && (unsigned)xx < (unsigned)p.fS;
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 const bool inimg = valid && (unsigned)(y0 - 1 + py) < (unsigned)p.fS && (unsigned)(x0 - 1 + px) < (unsigned)p.fS;
                 const float *raw = (const float *)(smem + OFF_R + rawb * RAWB);
                 const float *b1 = (const float *)(smem + OFF_R + 2 * RAWB);
-                const int porg = valid ? py * 36 + px : 0;
+                const int porg = valid ? py * RAWC + px : 0;
                 float xv[16];
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2) xv[s2] = raw[porg + koff1[s2]];
@@ -374,14 +382,14 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
         };
         auto load_patch = [&](int j, unsigned ccoff, char *dstbuf) {
-            if (!live || lw + 4 * j >= kPatchSlots) return;
+            if (!live || lw + 4 * j >= kPatchSlots || FUSE) return;
             const unsigned o = poff[j];
             glds(o == 0xFFFFFFFFu ? p.zero : (pfixed ? p.in + (o & 0xfffffu) : p.in + (size_t)o + ccoff), dstbuf + (lw + 4 * j) * 1024);
         };
         // patch stream state: the chunk being PREFETCHED: (p_it, p_cc), buffer pbuf
         int p_it = 0, p_cc = 0, pbuf = 0;
         auto next_patch_chunk = [&]() {
-            pbuf ^= 1;
+            if (NPB == 2) pbuf ^= 1;
             if (++p_cc == nchunks) {
                 p_cc = 0;
                 ++p_it;
@@ -389,18 +397,15 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         };
 
         if constexpr (FUSE) {
-            if (n_it > 0) {
-                load_raw(item0, 0);
-                if (n_it > 1) load_raw(item0 + istride, 1);
-            }
+            if (n_it > 0) load_raw(item0, 0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();               // every loader wave's share of the raw tiles (and the bias) is in LDS
             if (n_it > 0) {
                 int b_;
                 tile_origin(item0, b_, f_y0, f_x0);
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (lw + 4 * q < ((TH + 2) * RS + 31) / 32) first_conv_tile(lw + 4 * q, 0, smem);
+                for (int q = 0; q < FTJ; ++q)
+                    if (lw + 4 * q < FTILES) first_conv_tile(lw + 4 * q, 0, smem);
             }
         }
         if (n_it > 0) {
@@ -433,25 +438,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 issued = WL;
             }
             if constexpr (FUSE) {
-                // tap 0: the raw tile of the item after next; taps 1-3: one 32-pixel slice each of the NEXT item's patch
-                // (its raw tile arrived an item ago)
-                if (tap == 0) {
-                    if (p_it + 1 < n_it) issued += load_raw(item0 + (p_it + 1) * istride, (p_it + 1) & 1);
-                    if (p_it < n_it) {
-                        int b_;
-                        tile_origin(item0 + p_it * istride, b_, f_y0, f_x0);
-                    }
-                }
-                if (tap >= 1 && tap <= 3 && p_it < n_it && lw + 4 * (tap - 1) < ((TH + 2) * RS + 31) / 32) {
-                    // (this is bulk work with an item's worth of slack: it must not pre-empt the consumers' MFMA issue the way
-                    // the few DMA instructions of a step are meant to)
-                    if (TDRN_PATCH_PRIO >= 4) __builtin_amdgcn_s_setprio(0);
-                    first_conv_tile(lw + 4 * (tap - 1), p_it & 1, smem + pbuf * kPatchBytes);
-                    if (TDRN_PATCH_PRIO == 4) __builtin_amdgcn_s_setprio(2);
-                    if (TDRN_PATCH_PRIO == 5) __builtin_amdgcn_s_setprio(3);
-                }
+                // tap 0: the raw tile of the NEXT item (its patch is computed behind this item's last barrier, below)
+                if (tap == 0 && c_it + 1 < n_it) issued += load_raw(item0 + (c_it + 1) * istride, (c_it + 1) & 1);
             } else if (p_it < n_it && tap < 6) {
-                char *dstbuf = smem + pbuf * kPatchBytes;
+                char *dstbuf = smem + pbuf * PBYTES;
                 const unsigned ccoff = (unsigned)(p_cc * 128);
                 switch (tap) {
                     case 0:
@@ -483,6 +473,20 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 tap = 0;
                 next_patch_chunk();
                 if (++c_cc == nchunks) {
+                    if constexpr (FUSE) {
+                        // The item is finished: its patch is dead and the consumers are busy with their epilogue (no MFMA, no
+                        // patch reads): compute the NEXT item's patch into the same buffer now, then meet the consumers at the
+                        // extra barrier that releases their first reads of it.
+                        if (c_it + 1 < n_it) {
+                            int b_;
+                            tile_origin(item0 + (c_it + 1) * istride, b_, f_y0, f_x0);
+#pragma unroll
+                            for (int q = 0; q < FTJ; ++q)
+                                if (lw + 4 * q < FTILES) first_conv_tile(lw + 4 * q, (c_it + 1) & 1, smem);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
+                    }
                     c_cc = 0;
                     ++c_it;
                 }
@@ -494,8 +498,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 
     // =========================== CONSUMER ===========================
     const int r32 = lane & 31, hh = lane >> 5;
-    const int cw = wave & 3;                           // pixel group: pixels [64*cw, 64*cw+64)
-    const int chalf = wave >> 2;                       // cout half: couts [BNH*chalf, BNH*chalf + BNH) of the tile
+    const int cw = wave % PXG;                         // pixel group: pixels [64*cw, 64*cw+64)
+    const int chalf = wave / PXG;                      // cout group: couts [BNH*chalf, BNH*chalf + BNH) of the tile
     char *stg = smem + OFF_S + wave * SROWS * SSTRIDE;
     f32x16 acc[WC][2];
 
@@ -755,13 +759,15 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             if (++cc == nchunks) cc = 0;
         }
         wsb = smem + OFF_W + wslot * WBYTES;
-        psb = smem + pbuf * kPatchBytes;
+        psb = smem + (NPB == 2 ? pbuf : 0) * PBYTES;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             prow[pt] = base_i[pt] + delta + tq;
             psw[pt] = (prow[pt] >> 1) & 7;
         }
-        load_frags(wfA, pfA, 0);     // (past the last step this reads stale but in-bounds LDS; unused)
+        // (FUSE: behind an item's last barrier the single patch buffer is being rewritten: its first reads wait for the
+        // extra barrier after the epilogue)
+        if (!(FUSE && item_done)) load_frags(wfA, pfA, 0);     // (past the last step this reads stale but in-bounds LDS; unused)
         __builtin_amdgcn_sched_barrier(0);
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(1);
         mma_frags(wfB, pfB, m0, m1);
@@ -773,6 +779,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             if (it < n_it) {
                 setup_item(it);
                 init_acc(it);
+                if constexpr (FUSE) {
+                    __builtin_amdgcn_s_barrier();           // the loaders have written the next item's patch
+                    load_frags(wfA, pfA, 0);
+                }
             }
             STAMP(3);                                       // epilogue + next item's set-up
         }
@@ -802,7 +812,7 @@ template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p,
     if (p.max_wgs > 0 && grid > p.max_wgs) grid = p.max_wgs;
     if constexpr (BN == 64 && sizeof(DT) == 2) {
         if (p.fx) {
-            if (p.tw != 32 || p.n_tiles != 1) return TDRN_E_UNSUPPORTED;
+            if (p.tw != 32 || p.n_tiles != 1 || p.H % 16) return TDRN_E_UNSUPPORTED;
             hipLaunchKernelGGL((conv3x3_patch_kernel<DT, 64, 32, true>), dim3(grid), dim3(768), 0, s, p);
             return hip_status(hipGetLastError());
         }
@@ -830,7 +840,7 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     p.M = a.B * a.H * a.W;
     if (p.tw) {
         p.tiles_x = a.W / p.tw;
-        p.tiles_per_img = p.tiles_x * (a.H / (256 / p.tw));
+        p.tiles_per_img = p.tiles_x * (a.H / ((a.fuse_x ? 512 : 256) / p.tw));      // the fused first-conv variant works on 16 x 32 tiles
         p.m_tiles = a.B * p.tiles_per_img;
     } else {
         p.tiles_x = 0; p.tiles_per_img = 0;

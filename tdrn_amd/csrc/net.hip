@@ -615,7 +615,7 @@ struct tdrn_net {
                 int readers = 0;
                 for (const Op &o : ops) readers += (o.in == ops[0].out) + (o.res == ops[0].out);
                 if (c.in == ops[0].out && readers == 1 && c.k == 3 && c.stride == 1 && c.pad == 1 && c.dil == 1 && c.phases == 1 && c.res < 0 &&
-                    c.out_kind == OUT_TENSOR && c.Npad == 64 && c.Cin == 64 && ti.W % 32 == 0 && ti.H % 8 == 0 && ti.H == ti.W && c.lane == 0)
+                    c.out_kind == OUT_TENSOR && c.Npad == 64 && c.Cin == 64 && ti.W % 32 == 0 && ti.H % 16 == 0 && ti.H == ti.W && c.lane == 0)
                     fuse_first = 1;
                 if (fuse_first >= 0) {                   // the fused launch carries both layers' algorithmic work
                     ops[1].flops += ops[0].flops;
