@@ -256,7 +256,9 @@ TDRN_API int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_ent
  * forward on the same workspace: tdrn_net_tensor_info names tensor `index` after the parameter
  * that produced it (e.g. "backbone.3", "L2Norm_4_3", "pool:backbone.3"); tdrn_net_read_tensor
  * converts it to fp32 NCHW (B,C,H,W) into out_dev.  Used by tests/ to compare every stage with
- * the oracle; not part of the hot path. */
+ * the oracle; not part of the hot path.  Tensors that a fused launch never materialises are not written: full-resolution
+ * maps whose only reader is a fused max-pool, and -- in the 16-bit plans of the VGG trunks -- the first conv's output, which is
+ * computed inside the next conv's loader (environment TDRN_FUSE_FIRST=0 keeps it as its own launch). */
 TDRN_API int tdrn_net_tensor_count(const tdrn_net *net);
 TDRN_API int tdrn_net_tensor_info(const tdrn_net *net, int index, const char **label, int *C, int *H,
                                   int *W);
