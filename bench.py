@@ -18,8 +18,17 @@ The JSON line also carries
                  rocprofv3 PMC passes (profiles/pmc_traffic.json)
   parity       : the other half of BASELINE's metric ("box L-inf vs CPU ref"): decoded boxes and softmax scores of
                  the TIMED dtype (and of the fp32 and fp16 modes beside it) against the fp32 CPU oracle on one frame
+  modes        : the OTHER precisions of the same workload, each timed in this run as hipGraph replays (frames/s,
+                 ms_per_step, dominant-kernel fraction of ITS OWN peak: fp32 against the 157.3 TFLOP/s fp32 matrix peak)
+                 -- the fp32 mode is the one that meets north_star's "within 1e-3" clause
+  detections   : per precision, what the error does to the FINAL detections of >= 8 frames: (class, slot) rows of
+                 Detect's output against the oracle's Detect on the fp32 oracle outputs (identical occupancy, matched at
+                 IoU >= 0.9, moved > 1 px, appeared, vanished)
   cpu_baseline : the CPU oracle (torch-CPU convs + C deformable conv + C Detect) on a bounded sample
                  of the same workload on this host's cores (rank 0, N=1 only)
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N ranks (fresh child processes, one per
+GPU, RCCL over 127.0.0.1) BEFORE anything in this process touches a GPU and relays rank 0's JSON line.
 """
 import argparse
 import json
@@ -35,17 +44,22 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X_MICROAR
 GFLOP_PER_FRAME = {320: 77.466, 512: 198.314}                   # BASELINE.md section 2 (multihead)
 
 
-def pmc_traffic(kernel, args):
+def pmc_traffic(kernel, args, build):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
-    FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streams + WRITE_SIZE, both x1024), or None
-    when no pass exists for this exact workload."""
+    FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streams + WRITE_SIZE, both x1024).  It is a figure
+    FROM THE PROFILES, not a measurement of this run: (value, source) -- value is None when no pass exists for this
+    exact workload or when the passes were taken on another build of the library."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(path))
         e = d.get("%s|%d|%s|%d" % (kernel, args.size, args.dtype, args.batch))
-        return e["hbm_bytes_per_launch"] if e else None
+        if not e:
+            return None, "no PMC pass committed for this workload"
+        if e.get("build") and e["build"] != build:
+            return None, "profiles/pmc_traffic.json is of build %r, this run is %r" % (e["build"], build)
+        return e["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 PMC passes, %s): not measured in this run" % e.get("build", "build not recorded")
     except (OSError, ValueError, KeyError):
-        return None
+        return None, "profiles/pmc_traffic.json unreadable"
 
 
 NEAR_EPS = {"fp32": 1e-4, "bf16": 0.03, "fp16": 0.004}   # pixels with a deformable tap this close to a sampling discontinuity
@@ -122,6 +136,98 @@ def cpu_baseline(size, frames=2):
                       "conv + C Detect), %.1f s" % (frames, dt)}
 
 
+def detection_agreement(size, dtypes, dev, frames=8):
+    """What each precision's error does to the FINAL detections (layers/functions/detection.py:25-70): Detect (HIP) on the
+    HIP net's outputs against the oracle's Detect on the fp32 oracle's outputs, over `frames` synthetic frames, boxes in
+    the 500 x 375 pixel units evaluate.py uses.  Per dtype: rows (= occupied (image, class, slot) entries) on each side,
+    rows whose (class, slot) is occupied on both sides, greedy one-to-one matches at IoU >= 0.9 inside each (image, class),
+    matched rows that moved by more than 1 px in any coordinate, rows that appeared / vanished."""
+    import numpy as np
+    import torch
+    from oracle import net_ref
+    from oracle import oracle as orc
+    from tdrn_amd.layers import Detect
+    from tdrn_amd.model.dualrefinedet_vggbn import build_net
+    from tdrn_amd.utils import synth
+    net = build_net("test", size, 21, 1024, 1, True, True)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    x = synth.synth_frames(frames, size, seed=77)
+    cfg = dict(feature_maps=[size // 8, size // 16, size // 32, size // 64], min_dim=size, steps=[8, 16, 32, 64],
+               min_sizes=[32, 64, 128, 256], max_sizes=[], aspect_ratios=[[2]] * 4, variance=[0.1, 0.2], clip=True,
+               flip=True, name="bench")
+    pri = orc.prior_box(cfg)
+    scale = (500.0, 375.0, 500.0, 375.0)
+    ref = []
+    for i in range(frames):
+        arm, _, odm, conf = net_ref.drn_vggbn_forward(sd, x[i:i + 1], 21, True, True)
+        ref.append(np.asarray(orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), scale)[0])[0])     # (C, top_k, 5)
+    pri_d = torch.from_numpy(pri).to(dev)
+
+    def iou(a, b):
+        iw = np.clip(np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]), 0, None)
+        ih = np.clip(np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]), 0, None)
+        inter = iw * ih
+        aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        return inter / np.maximum(aa[:, None] + ab[None, :] - inter, 1e-12)
+    out = {"frames": frames, "box_unit": "pixels of a 500 x 375 frame", "reference": "oracle Detect on the fp32 CPU oracle's outputs"}
+    for dt in dtypes:
+        net.set_compute_dtype(dt)
+        r = net.engine(dev).forward(torch.from_numpy(x).to(dev))
+        got = Detect(21, 0, 200, 0.01, 0.45).forward(r["odm_loc"], r["conf"], pri_d, arm_loc_data=r["arm_loc"],
+                                                       scale=torch.tensor(scale)).cpu().numpy()
+        n_ref = n_got = same_slot = matched = moved = 0
+        for i in range(frames):
+            for c in range(1, 21):
+                a, b = ref[i][c], got[i][c]
+                ka, kb = a[:, 0] > 0, b[:, 0] > 0
+                n_ref += int(ka.sum()); n_got += int(kb.sum()); same_slot += int((ka & kb).sum())
+                if not ka.any() or not kb.any():
+                    continue
+                ba, bb = a[ka][:, 1:], b[kb][:, 1:]
+                m = iou(ba, bb)
+                used = np.zeros(len(bb), bool)
+                for j in range(len(ba)):                      # oracle rows in score order take their best free partner
+                    k = int(np.argmax(np.where(used, -1.0, m[j])))
+                    if not used[k] and m[j, k] >= 0.9:
+                        used[k] = True
+                        matched += 1
+                        moved += int(np.abs(ba[j] - bb[k]).max() > 1.0)
+        out[dt] = {"rows_oracle": n_ref, "rows_hip": n_got, "rows_same_class_slot": same_slot, "matched_iou_0.9": matched,
+                   "matched_moved_gt_1px": moved, "vanished": n_ref - matched, "appeared": n_got - matched}
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh ranks (one per GPU) before this process
+    has touched a GPU, relay rank 0's stdout (the one JSON line), exit non-zero if any rank does."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one_device = os.environ.get("TDRN_DIST_ONE_DEVICE") == "1"      # test-only: every rank on device 0 (needs TDRN_DIST_BACKEND=gloo)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_device else str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed: %r" % bad, file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,14 +238,20 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the box / score error block (one oracle forward on the host)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the box / score error and detection-agreement blocks (oracle forwards on the host)")
+    ap.add_argument("--no-modes", action="store_true", help="skip timing the other precisions")
     ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
     ap.add_argument("--graph", type=int, default=1, help="1: the step (forward + Detect) is one captured hipGraph replay; 0: eager launches")
+    ap.add_argument("--reps", type=int, default=9, help="the K-step loop is timed this many times; the MEDIAN repetition is reported")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps cycle through")
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=96)      # ~16 s of CPU work on the GPU box host
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                                  # (does not return)
 
     import torch
+    from tdrn_amd import _lib
     from tdrn_amd import dist as tdist
     from tdrn_amd.data import mb_cfg
     from tdrn_amd.layers import Detect, PriorBox
@@ -147,10 +259,13 @@ def main():
     from tdrn_amd.utils import synth
 
     rank, local_rank, world = tdist.init()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    build = _lib.lib().tdrn_version().decode()
 
     net = build_net("test", args.size, 21, 1024, 1, True, True)
     net.set_compute_dtype(args.dtype)
@@ -163,7 +278,10 @@ def main():
     else:
         eng = net.engine(dev)
     B = args.batch
-    x = torch.from_numpy(synth.synth_frames(B, args.size, seed=100 + rank)).to(dev)
+    NB = max(1, args.batches)
+    # NB distinct batches, all resident in HBM before the timed region; step k runs batch k % NB
+    xb = [torch.from_numpy(synth.synth_frames(B, args.size, seed=100 + rank + 1000 * j)).to(dev) for j in range(NB)]
+    x = xb[0]
     pri = PriorBox(mb_cfg["VOC_320" if args.size == 320 else "VOC_512_RefineDet"]).forward().to(dev)
     det = Detect(21, 0, 200, 0.01, 0.45)
     scale = [500.0, 375.0, 500.0, 375.0]
@@ -172,10 +290,9 @@ def main():
     # (shared weight blob), workspace and HIP stream, so that one slice's kernels fill the CUs another
     # slice's tail leaves idle and Detect overlaps the other slices' convolutions.
     NS = max(1, args.streams)
-    engines, streams, dets, xs = [eng], [torch.cuda.current_stream(dev)], [det], [x]
+    engines, streams, dets = [eng], [torch.cuda.current_stream(dev)], [det]
     if NS > 1:
         from tdrn_amd.engine import NetEngine
-        xs = list(torch.chunk(x, NS))
         for i in range(1, NS):
             e2 = NetEngine(**dict(net._engine_args, dtype=args.dtype))
             e2.share_weights(eng)
@@ -183,7 +300,8 @@ def main():
             streams.append(torch.cuda.Stream(dev))
             dets.append(Detect(21, 0, 200, 0.01, 0.45))
 
-    def step():
+    def eager_step(k):
+        xs = list(torch.chunk(xb[k % NB], NS))
         outs = []
         if NS > 1:
             start = torch.cuda.Event()
@@ -199,63 +317,82 @@ def main():
             streams[0].wait_stream(streams[i])
         return outs
 
-    if args.graph and NS == 1:
-        from tdrn_amd.engine import GraphedCall
-
+    def make_stepper(engine, detect):
+        """step(k) for one engine: with --graph, one captured hipGraph per resident batch (the batch lives in the graph's
+        input buffer: no per-step copy), replayed in turn."""
         def one_step(xin):
-            r = eng.forward(xin)
-            return r["conf"] if args.no_detect else det.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
-        graphed = GraphedCall(one_step, x)
-        x = graphed.inputs[0]                      # the batch lives in the captured input buffer: no per-step copy
+            r = engine.forward(xin)
+            return r["conf"] if args.no_detect else detect.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
+        if args.graph and NS == 1:
+            from tdrn_amd.engine import GraphedCall
+            graphs = [GraphedCall(one_step, xb[j]) for j in range(NB)]
+            return lambda k: graphs[k % NB](graphs[k % NB].inputs[0])
+        return lambda k: one_step(xb[k % NB])
 
-        def step():
-            return graphed(x)
-    for _ in range(args.warmup):
-        step()
-    tdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    tdist.barrier()
-    dt = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    step = make_stepper(eng, det) if NS == 1 else eager_step
+
+    def timed(stepper, steps, reps):
+        """`reps` repetitions of the K-step loop, each bracketed by barrier + synchronize on both sides and reduced with
+        MAX over ranks; returns the per-repetition times (s)."""
+        out = []
+        for _ in range(reps):
+            tdist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                stepper(k)
+            torch.cuda.synchronize()
+            tdist.barrier()
+            out.append(tdist.max_over_ranks(time.perf_counter() - t0, dev))
+        return out
+
+    for k in range(args.warmup):
+        step(k)
+    reps = sorted(timed(step, args.steps, max(1, args.reps)))
+    dt = reps[len(reps) // 2]                                    # the median repetition
     fps = world * B * args.steps / dt
 
     # ---- forward-only split and per-kernel roofline (separate, event-instrumented passes) ---------
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        eng.forward(x)
-    torch.cuda.synchronize()
-    fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
-
-    def profiled(mode):
-        eng.set_profile(mode)
-        eng.forward(x)
-        eng.forward(x)
+    def forward_ms(engine):
         torch.cuda.synchronize()
-        st = eng.kernel_stats()
-        ops = eng.op_stats() if args.per_op else None
-        eng.set_profile(0)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            engine.forward(x)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / 5 * 1e3
+    fwd_ms = forward_ms(eng)
+
+    def profiled(engine, mode):
+        engine.set_profile(mode)
+        engine.forward(x)
+        engine.forward(x)
+        torch.cuda.synchronize()
+        st = engine.kernel_stats()
+        ops = engine.op_stats() if args.per_op else None
+        engine.set_profile(0)
         return st, ops
-    stats, ops = profiled(1)                                 # every launch alone on one stream
-    stats_prod, ops_prod = profiled(2)                       # the production schedule (side lanes on)
+
+    def conv_family(stats):
+        """the 3x3 MFMA conv family of a step (conv3x3_patch.hip + conv3x3_pp.hip launches are accounted together)"""
+        return max(stats, key=lambda s: s["ms"])
+    stats, ops = profiled(eng, 1)                            # every launch alone on one stream
+    stats_prod, ops_prod = profiled(eng, 2)                  # the production schedule (side lanes on)
     if ops and rank == 0:
         prod = {o["name"]: o["ms"] for o in ops_prod}
         print("%-44s %11s %11s %8s %9s %8s" % ("launch", "alone us", "in step us", "GFLOP", "TFLOP/s", "GB"), file=sys.stderr)
         for o in ops:
             tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
             print("%-44s %11.1f %11.1f %8.1f %9.1f %8.3f" % (o["name"], o["ms"] * 1e3, prod.get(o["name"], 0.0) * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9), file=sys.stderr)
-    conv = max(stats_prod, key=lambda s: s["ms"])            # the dominant kernel family of the step
+    conv = conv_family(stats_prod)                           # the dominant kernel family of the step
     solo = next(s for s in stats if s["name"] == conv["name"])
     peak = PEAK_TFLOPS[args.dtype]
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     achieved_solo = solo["flops"] / (solo["ms"] * 1e-3) / 1e12 if solo["ms"] > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(conv["name"], args, build)
     # `achieved` / `frac` are the PRODUCTION figures: hipEvents on the stream each launch runs on, side lanes on -- what
     # rocprofv3 --kernel-trace sees in the timed loop.  The single-stream figures are given beside them.
     roofline = {"bound": "mfma", "kernel": conv["name"], "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(conv["name"], args),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": conv["launches"], "gflop_per_launch": round(conv["flops"] / 1e9 / conv["launches"], 2),
                 "us_per_launch": round(conv["ms"] * 1e3 / conv["launches"], 2), "mode": "production schedule (side lanes on)",
                 "single_stream": {"achieved": round(achieved_solo, 2), "frac": round(achieved_solo / peak, 4),
@@ -263,6 +400,29 @@ def main():
     solo_ms = {s["name"]: s["ms"] for s in stats}
     kernels = {s["name"]: {"ms": round(s["ms"], 4), "ms_single_stream": round(solo_ms.get(s["name"], 0.0), 4), "launches": s["launches"],
                            "gflop": round(s["flops"] / 1e9, 3), "gbyte": round(s["bytes"] / 1e9, 4)} for s in stats_prod}
+
+    # ---- the other precisions of the same workload, timed in this run (N = 1 only) -----------------------------------
+    modes = None
+    if world == 1 and NS == 1 and not args.no_modes:
+        modes = {}
+        for dtm in [d for d in ("fp16", "fp32", "bf16") if d != args.dtype]:
+            net.set_compute_dtype(dtm)
+            e2 = net.engine(dev)
+            st2 = make_stepper(e2, Detect(21, 0, 200, 0.01, 0.45))
+            k_steps = max(5, min(args.steps, 10 if dtm == "fp32" else args.steps))
+            for k in range(3):
+                st2(k)
+            r2 = sorted(timed(st2, k_steps, 3))
+            t2 = r2[len(r2) // 2]
+            sp, _ = profiled(e2, 2)
+            c2 = conv_family(sp)
+            a2 = c2["flops"] / (c2["ms"] * 1e-3) / 1e12 if c2["ms"] > 0 else 0.0
+            modes[dtm] = {"frames_per_s": round(B * k_steps / t2, 2), "ms_per_step": round(t2 / k_steps * 1e3, 4), "steps": k_steps,
+                          "repetitions": 3, "forward_only_ms_per_step": round(forward_ms(e2), 4),
+                          "roofline": {"kernel": c2["name"], "achieved": round(a2, 2), "peak": PEAK_TFLOPS[dtm], "unit": "TFLOP/s",
+                                       "frac": round(a2 / PEAK_TFLOPS[dtm], 4)}}
+            del st2, e2
+        net.set_compute_dtype(args.dtype)
 
     if rank == 0:
         line = {
@@ -274,18 +434,27 @@ def main():
                                    "VOC-shaped frames + synthetic weights" %
                                    (args.size, args.size, args.dtype, B, "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
                        "global_batch": world * B, "parallelism": "frame-sharded x%d, no per-frame collective" % world,
-                       "launch": "hipGraph replay" if (args.graph and NS == 1) else "eager"},
+                       "launch": "hipGraph replay" if (args.graph and NS == 1) else "eager",
+                       "resident_batches": NB},
+            "repetitions": {"n": len(reps), "reported": "median", "ms_per_step_min": round(reps[0] / args.steps * 1e3, 4),
+                            "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
             "fps_per_gpu": round(fps / world, 2),
             "forward_only_ms_per_step": round(fwd_ms, 4),
             "forward_tflops": round(GFLOP_PER_FRAME.get(args.size, 0) * B / fwd_ms, 2),
+            "build": build,
             "roofline": roofline,
             "kernels": kernels,
         }
+        if modes is not None:
+            line["modes"] = modes
         if not args.no_parity:
-            par = parity_vs_oracle(args.size, [args.dtype] + [d for d in ("fp32", "fp16") if d != args.dtype], dev)
+            others = [d for d in ("fp32", "fp16", "bf16") if d != args.dtype]
+            par = parity_vs_oracle(args.size, [args.dtype] + others, dev)
             line["parity"] = par
             line["box_linf"] = par[args.dtype]["box_linf"]              # the timed dtype's figure; fp32 mode: par["fp32"]
             line["score_linf"] = par[args.dtype]["score_linf"]
+            if world == 1:
+                line["detections"] = detection_agreement(args.size, [args.dtype] + others, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_frames)
         print(json.dumps(line))

@@ -830,6 +830,10 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     const int mode = patch_conv_supported(a);
     if (!mode) return TDRN_E_UNSUPPORTED;
     if (out_pool && (mode < 0 || (a.H & 1) || (a.W & 1))) return TDRN_E_UNSUPPORTED;
+    if (!out_pool && pp_conv_supported(a)) {             // conv3x3_pp.hip: same arithmetic, same bits
+        const int rc = launch_conv3x3_pp(a, out_pool, s);
+        if (rc != TDRN_E_UNSUPPORTED) return rc;         // (it declines launches too small to fill the chip)
+    }
     PatchParams p;
     p.in = (const char *)a.in; p.w = (const char *)a.w; p.zero = (const char *)a.zero_page; p.bias = a.bias;
     p.out = (char *)a.out; p.out_pool = (char *)out_pool;

@@ -1,0 +1,873 @@
+// conv3x3_pp.hip -- 3x3 / stride 1 / pad 1 convolution for the Cin >= 128, Cout % 256 == 0 layers of the 16-bit plans
+// (conv3_x, conv4_x, the 40x40 TCB convs: ~2/3 of the network's FLOPs) as an ALL-WAVES-COMPUTE direct convolution:
+// eight waves per workgroup, one workgroup per CU, every wave owns a 64-pixel x 128-cout accumulator tile (128
+// registers), item = 256 pixels x 256 couts.  The two waves of a SIMD alternate ("ping-pong"): while the waves of
+// group 0 (waves 0-3, couts 0-127) multiply, the waves of group 1 (waves 4-7, couts 128-255) read their next operand
+// fragments from LDS and issue their share of the LDS-DMA stream, and vice versa -- every interval between two
+// s_barriers has one wave per SIMD in a bare 16-MFMA segment (512 cycles) and its partner in a load segment.
+//
+// Why a second kernel next to conv3x3_patch.hip (4 loader + 8 consumer waves, 64 x 64 per consumer): that structure
+// tops out at 0.49 of the MFMA peak with NO loads at all (both consumer waves of a SIMD run the same read->multiply
+// program in lockstep, profiles/r02_final), and its 3-waves-per-SIMD register budget cannot hold a bigger tile.
+// With two waves per SIMD a wave holds 128 accumulators, so a (chunk, tap) step is 32 MFMAs per wave for 24
+// ds_read_b128 (1.33 MFMA per read against 1.0) and a step's LDS-DMA volume per MFMA cycle is 18 B/clk against
+// 20.5 -- at twice the work between the waits of one step.
+//
+// What is kept from the patch kernel (and makes this bit-identical to it: same K order per output element):
+//   * the activation PATCH of the tile (256 pixels + 1-pixel halo, <= 352 rows of 128 B) is staged once per
+//     64-channel chunk and the nine taps are shifted row addresses into it (2 buffers);
+//   * the [256 x 128 B] weight slice of every (chunk, tap) step goes through a 2-slot ring, one step ahead; each
+//     group stages and reads only its own half of a slot, so the two halves are private rings;
+//   * bank swizzle on the SOURCE address of every LDS-DMA piece, raw s_barrier, counted s_waitcnt vmcnt(N) once per
+//     step, accumulators start at the bias, epilogue through a wave-private LDS strip -> whole-line NHWC stores with
+//     ReLU and the optional MaxPool2d(2,2) fused.  The strip lives in the patch buffer that died with the item's
+//     last step (there is no LDS left for a dedicated one).
+//
+// Interval timeline (g = step, one interval = the span between two consecutive barriers; L = load segment,
+// M = 16 MFMAs):
+//     interval 4g+0 : group 0  L(g, K-slices 0-1), prepares a patch piece       group 1  M(g-1, slices 2-3)
+//     interval 4g+1 : group 0  M(g, 0-1) + weight pieces 2,3 of step g+1        group 1  L(g, 0-1)
+//                               + the patch piece of the next chunk
+//     interval 4g+2 : group 0  L(g, 2-3)                                        group 1  M(g, 0-1) + its pieces
+//     interval 4g+3 : group 0  M(g, 2-3) + weight pieces 0,1 of step g+2,       group 1  L(g, 2-3)
+//                               then vmcnt(2): all of step g+1 has landed
+// The LDS-DMA pieces are issued INSIDE the multiply segments, one between two groups of four MFMAs (an MFMA holds a
+// wave's issue for 8 of its 32 cycles: the piece hides in the gap); issued in the load segments (first version: 4-5
+// pieces of ~100+ cycles each next to 12 reads) they stretched those past the 512 cycles of the partner's multiply.
+// Ordering rules (cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it"): a piece is
+// read only behind the issuing wave's counted vmcnt AND a later barrier; a buffer is re-filled only behind a barrier
+// that every reader passed after an lgkmcnt(0).
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+#ifndef TDRN_PP_ABLATE
+#define TDRN_PP_ABLATE 0      // diagnostics: 1 = no LDS-DMA, 2 = no ds_read/MFMA, 4 = no epilogue stores, 8 = no patch pieces, 16 = no weight pieces
+#endif
+
+namespace tdrn {
+
+struct PPParams {
+    const char *in, *w, *zero;
+    const float *bias;
+    char *out, *out_pool;          // NHWC [B][H][W][Cs] and optional pooled [B][H/2][W/2][Cs]
+    int B, H, W, Cin, Cout, Cs, Ktot;
+    int relu;
+    int tiles_x, tiles_per_img;    // 2-D tiles
+    int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
+    int M;                         // B*H*W
+    // chained split ("stream-K", see the kernel): fp32 accumulator slabs [workgroup][8 waves][32][64 lanes][4] and one flag
+    // word per workgroup; null = whole items only
+    float *sk_slab;
+    unsigned *sk_flag;
+#ifdef TDRN_PP_STAMP
+    unsigned *stamps;              // diagnostics build only: [workgroup][wave][10] cycle sums (s_memtime), see the launcher
+#endif
+};
+
+// In-kernel cycle stamps of a diagnostics build (make EXTRA=-DTDRN_PP_STAMP; never in the product): one s_memtime at every
+// barrier of a step, before and after; the differences are formed once per step, behind the step's last barrier (s_memtime
+// returns through lgkmcnt: reading a stamp earlier would drain the LDS reads of a load segment).
+#ifdef TDRN_PP_STAMP
+#define PPT(k) st_t[k] = __builtin_amdgcn_s_memtime()
+#else
+#define PPT(k) do { } while (0)
+#endif
+
+namespace {
+
+template <typename DT> struct MmaPP;
+template <> struct MmaPP<bf16_t> {
+    __device__ static __forceinline__ void run(const u32x4 &a, const u32x4 &b, f32x16 &c)
+    { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(i16x8, a), __builtin_bit_cast(i16x8, b), c, 0, 0, 0); }
+};
+template <> struct MmaPP<f16_t> {
+    __device__ static __forceinline__ void run(const u32x4 &a, const u32x4 &b, f32x16 &c)
+    { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); }
+};
+
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at lds_dst + 16*lane) from a wave-uniform base plus a 32-bit per-lane
+// byte offset.  Inline asm on purpose: (1) no 64-bit per-lane address arithmetic (the accumulators need the registers),
+// (2) hipcc's waitcnt pass does not see it, so it cannot put an `s_waitcnt vmcnt(0)` in front of the ds_reads that follow
+// (cdna_hip_programming.md 5.7 item 1: the completion is counted by hand -- the vmcnt(N) of every step below).  M0 is
+// written in the statement that uses it and restored.
+__device__ __forceinline__ void glds16(const char *sbase, unsigned voff, unsigned lds_dst)
+{
+    if constexpr (!(TDRN_PP_ABLATE & 1)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
+    }
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
+}
+
+// (all waves of a workgroup take part in every barrier; nothing may move across it)
+#define PP_BAR()                                  \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+#define PP_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define PP_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)   // vmcnt(0), through the builtin: the compiler's waitcnt pass sees it
+
+constexpr int kPPSlots = 44;                      // 8-row LDS-DMA pieces per patch buffer (352 rows)
+constexpr int kPPPieces = (kPPSlots + 7) / 8;     // patch pieces per wave and chunk (6: one per tap 0..5)
+
+}  // namespace
+
+// TW = 32 / 16: 2-D tiles of (256/TW) x TW pixels of one image; TW = 0: flat tiles of 256 consecutive NHW pixels.
+// POOL: the instantiation that also (or only) writes the fused MaxPool2d(2,2) output (two layers of a VGG trunk); kept apart so
+// that the other layers' register allocation does not carry the pooled epilogue.
+template <typename DT, int TW, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
+{
+    static_assert(sizeof(DT) == 2, "16-bit element types only");
+    constexpr bool FLAT = TW == 0;
+    constexpr int LGTW = TW == 32 ? 5 : 4;
+    constexpr int TH = TW ? 256 / TW : 0;
+    constexpr int ES = 2, P16 = 8;
+    constexpr int BN = 256, BNH = 128, WC = 4;
+    constexpr int PBYTES = kPPSlots * 1024;
+    constexpr int WBYTES = BN * 128;                    // one weight slot: 32 KiB (two group halves of 16 KiB)
+    constexpr int OFF_W = 2 * PBYTES;
+    constexpr int OFF_B = OFF_W + 2 * WBYTES;
+    constexpr int OFF_Z = OFF_B + 1024;                 // 128 zero bytes: where a flat tile's out-of-image taps read
+    constexpr int LDS = OFF_Z + 128;
+    constexpr int SROWS = 16;                           // pixels per epilogue round (per wave)
+    constexpr int SSTRIDE = BNH * ES + 16;              // staging row stride (bytes)
+    constexpr int STRIP = SROWS * SSTRIDE;              // a wave's staging strip inside the dead patch buffer
+    static_assert(8 * STRIP <= PBYTES, "staging strips fit the dead patch buffer");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+
+    const int lane = threadIdx.x & 63;
+    // Register discipline: the 128 accumulators + 48 fragment registers leave ~70 for everything else, and hipcc hoists every
+    // loop-invariant lane expression of the (rarely executed) staging / epilogue code out of the step loop and then spills
+    // them -- re-loaded behind an `s_waitcnt vmcnt(0)` that would drain the LDS-DMA pipeline.  So those code paths derive
+    // their lane constants from an OPAQUE copy of the lane id (a few vector instructions where they are used).
+    auto opaque_lane = [&]() -> int {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2;                          // cout half / ping-pong group
+    const int cw = wave & 3;                            // pixel group: pixels [64*cw, 64*cw + 64)
+    const int nchunks = p.Cin / 64;
+
+    // ---- work distribution.  Each XCD label (blockIdx % 8) owns a contiguous range of items (cout siblings and
+    // neighbouring tiles share its L2).  A workgroup's work is a list of SEGMENTS (item, chunks [c0, c1)):
+    //   * whole-item mode: items item0, item0 + istride, ... (as conv3x3_patch.hip);
+    //   * chained split mode (sk_slab != null; "stream-K"): the XCD's (item, chunk) units are cut into EQUAL contiguous
+    //     ranges, one per workgroup, so a range may begin and end inside an item.  The workgroup that owns the first part of a
+    //     split item writes its fp32 accumulators to a slab; the owner of the rest STARTS from them -- the K order of every
+    //     output element is exactly that of an unsplit item, so the result does not depend on where the cuts fall (i.e. on
+    //     the batch size): bit-identical to whole-item mode.  800 items on 256 CUs take 3.125 item times instead of 4; and
+    //     the workgroups reach their epilogues at different times instead of all bursting their stores at once.
+    //     A workgroup runs its unfinished LAST item first (its successor needs that slab), whole items next, and the item
+    //     whose first part belongs to its predecessor last (the slab has long been written by then).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = (p.items + 7) >> 3, istride = ((int)gridDim.x + 7) >> 3;
+    int avail = p.items - xcd * per_xcd;
+    avail = avail < per_xcd ? avail : per_xcd;
+    avail = avail < 0 ? 0 : avail;
+    const bool sk = p.sk_slab != nullptr;
+    int n_seg, seg_item0, c0_first = 0, c1_last = nchunks, tail_first = 0, head_last = 0, n_steps;
+    if (sk) {
+        const int units = avail * nchunks;
+        // (units * 32 < 2^31 for any tensor below the 4-GiB limit of patch_conv_supported; 32-bit scalar arithmetic)
+        const int u0 = __builtin_amdgcn_readfirstlane(units * slot / istride), u1 = __builtin_amdgcn_readfirstlane(units * (slot + 1) / istride);
+        if (u1 <= u0) return;                           // (whole workgroup)
+        const int fi = u0 / nchunks, li = (u1 - 1) / nchunks;
+        n_seg = li - fi + 1;
+        seg_item0 = xcd * per_xcd + fi;
+        c0_first = u0 - fi * nchunks;
+        c1_last = u1 - li * nchunks;
+        tail_first = (c1_last != nchunks && n_seg > 1) ? 1 : 0;
+        head_last = (c0_first != 0 && n_seg > 1) ? 1 : 0;
+        n_steps = (u1 - u0) * 9;
+    } else {
+        n_seg = avail > slot ? (avail - slot + istride - 1) / istride : 0;
+        if (n_seg == 0) return;                         // (whole workgroup)
+        seg_item0 = xcd * per_xcd + slot;
+        n_steps = n_seg * nchunks * 9;
+    }
+    // segment k of the execution order -> item and chunk range (wave-uniform scalars)
+    auto seg = [&](int k, int &item, int &c0, int &c1) {
+        if (!sk) {
+            item = seg_item0 + k * istride; c0 = 0; c1 = nchunks;
+            return;
+        }
+        int j = k - tail_first + head_last;
+        if (tail_first && k == 0) j = n_seg - 1;
+        else if (head_last && k == n_seg - 1) j = 0;
+        item = __builtin_amdgcn_readfirstlane(seg_item0 + j);
+        c0 = __builtin_amdgcn_readfirstlane(j == 0 ? c0_first : 0);
+        c1 = __builtin_amdgcn_readfirstlane(j == n_seg - 1 ? c1_last : nchunks);
+    };
+    const int my_wg = xcd * istride + slot;             // slab / flag index (the producer's); the consumer reads my_wg - 1
+    const int RS = TW ? TW + 2 : p.W;                   // patch row stride of one image row
+
+    // =========================== staging (LDS-DMA) state ===========================
+    // Nothing per piece is kept in registers (the accumulators and fragments need them): a patch piece's source
+    // address is recomputed in the load segment that issues it (~25 vector instructions; those segments have slack).
+    int pt_b = 0, pt_y0 = 0, pt_x0 = 0;                 // 2-D: image and origin (incl. halo) of the tile being prefetched
+    int pt_j0 = 0;                                      // flat: NHW pixel of patch row 0 (M = B*H*W < 2^31)
+    auto patch_tile = [&](int item) {                   // (wave-uniform scalars; once per prefetched chunk)
+        const int mt = item / p.n_tiles;
+        if (TW) {
+            const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
+            const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+            pt_b = __builtin_amdgcn_readfirstlane(b); pt_y0 = __builtin_amdgcn_readfirstlane(ty * TH - 1); pt_x0 = __builtin_amdgcn_readfirstlane(tx * TW - 1);
+        } else {
+            pt_j0 = __builtin_amdgcn_readfirstlane(mt * 256 - p.W - 1);
+        }
+    };
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    // A patch piece is PREPARED in a load segment (source offset, which lanes are inside the image; lanes outside get their
+    // zeros by an ordinary LDS store right there) and ISSUED in the following multiply segment, between two MFMA groups.
+    unsigned pp_voff = 0, pp_dst = 0;                   // prepared piece: per-lane source offset, LDS destination
+    bool pp_ok = false, pp_any = false;                 // per-lane: inside the image; wave-uniform: any lane is
+    // my row of piece j is patch row pr = (wave + 8j)*8 + lane/8: (py, px) = (pr / RS, pr % RS) advance by 64 rows per piece
+    // (kept incrementally: two registers instead of a division per step); the swizzle term of the row does not depend on j
+    int pp_yx = 0;                                      // (py << 8) | px, one register
+    auto prep_patch = [&](int j, unsigned ccoff, int dstbuf_off) {   // dstbuf_off: byte offset of the patch buffer in smem
+        const int q = wave + 8 * j;                     // piece = patch rows [8q, 8q + 8)
+        pp_any = false;
+        if (q >= kPPSlots) return;                      // (wave-uniform)
+        const int ln = opaque_lane();
+        const int lrow = ln >> 3, pc = ln & 7;
+        const unsigned lc = (unsigned)((pc ^ ((4 * wave + (lrow >> 1)) & 7)) << 4) + ccoff;
+        const unsigned rowbytes = (unsigned)(p.Cin * ES);
+        unsigned off;                                   // (the tensor is < 4 GiB: patch_conv_supported)
+        bool ok;
+        if (TW) {
+            if (j == 0) {
+                const int pr = wave * 8 + lrow;
+                const int py0 = pr / RS;
+                pp_yx = (py0 << 8) | (pr - py0 * RS);
+            } else {
+                pp_yx += ((64 / RS) << 8) | (64 % RS);
+                if ((pp_yx & 0xff) >= RS) pp_yx += 256 - RS;
+            }
+            const int pp_py = pp_yx >> 8, pp_px = pp_yx & 0xff;
+            const int y = pt_y0 + pp_py, x = pt_x0 + pp_px;
+            ok = pp_py < TH + 2 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            off = (unsigned)((pt_b * p.H + y) * p.W + x) * rowbytes;
+        } else {
+            const int pr = q * 8 + lrow;
+            const int pix = pt_j0 + pr;
+            ok = pr < 256 + 2 * p.W + 2 && pix >= 0 && pix < p.M;
+            off = (unsigned)pix * rowbytes;
+        }
+        // rows outside the image (the conv's zero padding) and beyond the patch are ZEROED by an ordinary LDS store of the
+        // lanes concerned; the LDS-DMA runs with those lanes switched off (an inactive lane writes nothing)
+        const int piece = dstbuf_off + q * 1024;
+        if (!ok) {
+            unsigned z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));  // (materialised HERE: a hoisted zero is one more register to spill)
+            *(u32x4 *)(smem + piece + ln * 16) = u32x4{z, z, z, z};
+        }
+        pp_voff = off + lc;
+        pp_ok = ok;
+        pp_any = __builtin_amdgcn_ballot_w64(ok) != 0ull;   // a piece wholly outside the image issues NO DMA
+        pp_dst = __builtin_amdgcn_readfirstlane(smem_lds + piece);
+    };
+    auto issue_patch = [&]() {
+        if (pp_any) {
+            if (pp_ok && !(TDRN_PP_ABLATE & 8)) glds16(p.in, pp_voff, __builtin_amdgcn_readfirstlane(pp_dst));
+        }
+    };
+    // my group's half of a weight slot: rows grp*128 + (cw + 4k)*8 + lrow, k = 0..3 (the swizzle term is the same for all k).
+    // The four pieces of step s are issued in two multiply segments: pieces 0,1 in M(s-2, slices 2-3) -- right behind the last
+    // reads of the slot's previous tenant, step s-2 -- and pieces 2,3 in M(s-1, slices 0-1); they are waited for at the end
+    // of M(s-1, slices 2-3), >= 1000 cycles after the last of them was issued.
+    const unsigned wo = (unsigned)((grp * 128 + cw * 8 + (lane >> 3)) * p.Ktot * ES) + (unsigned)((((lane & 7) ^ ((4 * cw + (lane >> 4)) & 7)) << 4));
+    const unsigned wstep = (unsigned)(32u * p.Ktot * ES);
+    // weight stream: the step whose slice is started next is (segment w_k, chunk w_cc < w_c1, tap w_tap)
+    int w_k = 0, w_cc = 0, w_c1 = 0, w_tap = 0, w_slot = 0;
+    unsigned wbase = 0, wk = 0;                         // byte offsets into p.w (32-bit scalars: a 64-bit pointer that hipcc cannot
+                                                        // prove wave-uniform lands in a VGPR pair -- and is spilled)
+    unsigned pend_off = 0;                              // the step whose pieces 0,1 are out and 2,3 are not: source offset and LDS slot half
+    unsigned pend_dst = 0;
+    auto weight_seg = [&]() {                           // position the stream at the start of segment w_k
+        int item, c0;
+        seg(w_k, item, c0, w_c1);
+        w_cc = c0;
+        wbase = (unsigned)__builtin_amdgcn_readfirstlane((item % p.n_tiles) * BN * p.Ktot * ES);
+        wk = (unsigned)(w_cc * 128);
+    };
+    auto weights_begin = [&]() {                        // start the next step of the stream: sets pend_*, advances the cursor
+        pend_dst = __builtin_amdgcn_readfirstlane(smem_lds + OFF_W + w_slot * WBYTES + grp * (WBYTES / 2) + cw * 1024);
+        pend_off = __builtin_amdgcn_readfirstlane(wbase + wk);
+        w_slot ^= 1;
+        wk += (unsigned)(p.Cin * ES);
+        if (++w_tap == 9) {
+            w_tap = 0;
+            if (++w_cc == w_c1) {
+                ++w_k;
+                if (w_k < n_seg) weight_seg();
+            } else {
+                wk = (unsigned)(w_cc * 128);
+            }
+        }
+    };
+    auto weight_piece = [&](int k) {
+        unsigned w = wo;
+        asm volatile("" : "+v"(w));                     // (or hipcc keeps wo + k*wstep, k = 1..3, live across the loop -- and spills them)
+        if (!(TDRN_PP_ABLATE & 16)) glds16(p.w + pend_off, w + k * wstep, __builtin_amdgcn_readfirstlane(pend_dst + k * 4096));
+    };
+    // patch stream: the chunk being PREFETCHED is (segment p_k, chunk p_cc < p_c1) of item p_item, into buffer p_buf
+    int p_k = 0, p_cc = 0, p_c1 = 0, p_item = 0, p_buf = 0;
+    auto patch_seg = [&]() { seg(p_k, p_item, p_cc, p_c1); };
+    auto next_patch_chunk = [&]() {
+        p_buf ^= 1;
+        if (++p_cc == p_c1) {
+            ++p_k;
+            if (p_k < n_seg) patch_seg();
+        }
+    };
+    auto load_bias = [&](int item) {                    // wave 0: the item's 256 biases = one 1-KiB piece
+        glds16((const char *)(p.bias + (item % p.n_tiles) * BN), (unsigned)opaque_lane() * 16u, smem_lds + OFF_B);
+    };
+
+    // =========================== compute state ===========================
+    f32x16 acc[WC][2];
+    unsigned tapmask[2] = {0x1FFu, 0x1FFu};             // flat mode: bit t = tap t inside the image
+    constexpr int CPR = BNH * ES / 16;                  // 16-B chunks per pixel (my cout half): 16
+    constexpr int RPI = 64 / CPR;                       // staging rows copied per wave pass: 4
+    constexpr bool compute = !(TDRN_PP_ABLATE & 2);
+
+    int cur_mt = -1, n0 = 0;
+    long long tile_pix0 = 0;                            // 2-D: global pixel of the tile's (0,0); flat: mt*256
+    int tile_row0 = 0, tile_x0 = 0;                     // 2-D: b*H + y and x of the tile's (0,0)
+    auto setup_item = [&](int item) {
+        const int mt = item / p.n_tiles;
+        n0 = (item - mt * p.n_tiles) * BN;
+        if (mt == cur_mt) return;
+        cur_mt = mt;
+        if (TW) {
+            const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
+            const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+            tile_row0 = b * p.H + ty * TH;
+            tile_x0 = tx * TW;
+            tile_pix0 = (long long)tile_row0 * p.W + tile_x0;
+            return;
+        }
+        tile_pix0 = (long long)mt * 256;
+        const int r32 = opaque_lane() & 31;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const long long m = tile_pix0 + cw * 64 + pt * 32 + r32;
+            unsigned mk = 0;
+            if (m < p.M) {
+                const int rem = (int)(m % ((long long)p.H * p.W));
+                const int y = rem / p.W, x = rem - y * p.W;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mk |= 1u << t;
+                }
+            }
+            tapmask[pt] = mk;
+        }
+    };
+
+    // ---- epilogue of one item (wave-private staging strip in the dead patch buffer -> whole-line stores) ----------
+    auto epilogue = [&](char *stg) {
+        // lane-derived constants are re-derived here from an opaque copy of the lane id: hoisted out of the step loop they
+        // would be live (or spilled and re-loaded behind a vmcnt(0)) across every multiply segment
+        const int ln = opaque_lane();
+        const int r32 = ln & 31, hh = ln >> 5;
+        const int my_ch = ln % CPR, my_row = ln / CPR;
+        const int my_c = n0 + grp * BNH + my_ch * P16;
+        auto pixel_of = [&](int i) -> long long {       // global pixel of tile-local pixel i (or -1)
+            if (TW) return tile_pix0 + (long long)(i >> LGTW) * p.W + (i & (TW - 1));
+            const long long m = tile_pix0 + i;
+            return m < p.M ? m : -1;
+        };
+        // one 4-cout quad of one accumulator tile -> (ReLU, convert) -> staging row (the bias is already in)
+        auto stage_quad = [&](const f32x16 &t, int ci, int g, int srow) {
+            float q4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q4[j] = p.relu ? fmaxf(t[4 * g + j], 0.f) : t[4 * g + j];
+            char *d = stg + srow * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * ES;
+            *(uint2 *)d = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
+        };
+        if (p.out && !(TDRN_PP_ABLATE & 4)) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll 1
+                for (int rd = 0; rd < 32 / SROWS; ++rd) {
+                    if (r32 / SROWS == rd) {            // lanes whose pixel is in this round
+#pragma unroll
+                        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, r32 % SROWS);
+                    }
+                    PP_LGKM0();                         // my LDS writes are done
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < SROWS / RPI; ++k) {
+                        const int row = my_row + k * RPI;
+                        const long long gp = pixel_of(cw * 64 + pt * 32 + rd * SROWS + row);
+                        if (gp >= 0 && my_c < p.Cout)
+                            *(u32x4 *)(p.out + ((size_t)gp * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
+                    }
+                    __builtin_amdgcn_wave_barrier();     // (a wave's DS instructions execute in order)
+                }
+            }
+        }
+        if constexpr (POOL && TW != 0) if (p.out_pool) {
+            // fused MaxPool2d(2,2) on the RAW accumulators (max commutes with the monotonic bias+ReLU applied at
+            // staging): the partner row is my other pixel tile (TW = 32) or lane^16 (TW = 16); the partner column is
+            // lane^1.  Even-x lanes of the top row hold the result.
+            const int PW = p.W >> 1;
+            constexpr int npool = TW == 32 ? 16 : 8;    // pooled pixels per pixel tile
+            const bool holder = (r32 & 1) == 0 && (TW == 32 || r32 < 16);
+            const int prow_l = r32 >> 1;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                if (TW == 32 && pt == 1) break;
+#pragma unroll
+                for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[ci][pt][e];
+                        if (TW == 32) v = fmaxf(v, acc[ci][1][e]);
+                        else v = fmaxf(v, __shfl_xor(v, 16, 64));
+                        v = fmaxf(v, __shfl_xor(v, 1, 64));
+                        acc[ci][pt][e] = v;
+                    }
+#pragma unroll 1
+                for (int rd = 0; rd < (npool + SROWS - 1) / SROWS; ++rd) {
+                    if (holder && prow_l / SROWS == rd) {
+#pragma unroll
+                        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, prow_l % SROWS);
+                    }
+                    PP_LGKM0();
+                    __builtin_amdgcn_wave_barrier();
+                    const int rows_here = (npool - rd * SROWS) < SROWS ? (npool - rd * SROWS) : SROWS;
+#pragma unroll
+                    for (int k = 0; k < SROWS / RPI; ++k) {
+                        const int row = my_row + k * RPI;
+                        if (row < rows_here && my_c < p.Cout) {
+                            const int pl = rd * SROWS + row;            // pooled pixel within this pixel tile
+                            const int i0 = cw * 64 + pt * 32 + 2 * pl;  // top-left pixel of the 2x2 window
+                            const long long gpool = (long long)((tile_row0 + (i0 >> LGTW)) >> 1) * PW + ((tile_x0 + (i0 & (TW - 1))) >> 1);
+                            *(u32x4 *)(p.out_pool + ((size_t)gpool * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    };
+
+    // accumulators start at the bias (one 1-KiB LDS slot, re-staged by wave 0 late in the previous item)
+    auto init_acc = [&]() {
+        const int hh = opaque_lane() >> 5;
+        const char *bsrc = smem + OFF_B;
+#pragma unroll
+        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4 *)(bsrc + (grp * BNH + ci * 32 + 8 * g + 4 * hh) * 4);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ci][pt][4 * g + j] = bv[j];
+            }
+    };
+
+    // ---- chained split: a segment that starts inside an item continues from its predecessor's partial sums; one that ends
+    // inside an item hands its own on.  Slab image = the accumulator registers as they stand: [wave][quad 0..31][lane] x 16 B,
+    // every access a contiguous 1 KiB per wave.  Hand-off = cdna_hip_programming.md Guideline 16: plain stores, every storing
+    // wave's vmcnt(0), workgroup barrier, ONE agent-scope release + vmcnt(0), relaxed agent flag store; the consumer polls
+    // relaxed (bounded), ONE agent-scope acquire + vmcnt(0), workgroup barrier, plain loads.  The flag words are zeroed by a
+    // memset node in front of every launch.  Each of the two routines contains ONE workgroup barrier.
+    auto slab_of = [&](int wg) -> f32x4 * { return (f32x4 *)(p.sk_slab + ((size_t)wg * 8 + wave) * (32 * 64 * 4)) + opaque_lane(); };
+    auto begin_acc = [&](int c0) {
+        if (c0 == 0) {
+            init_acc();
+            return;
+        }
+        if (wave == 0) {
+            if (lane == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.sk_flag + (my_wg - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 20))
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BAR();
+        const f32x4 *src = slab_of(my_wg - 1);
+#pragma unroll
+        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = src[((ci * 2 + pt) * 4 + q) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ci][pt][4 * q + j] = v[j];
+                }
+    };
+    auto write_partial = [&]() {
+        f32x4 *dst = slab_of(my_wg);
+#pragma unroll
+        for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[((ci * 2 + pt) * 4 + q) * 64] = f32x4{acc[ci][pt][4 * q], acc[ci][pt][4 * q + 1], acc[ci][pt][4 * q + 2], acc[ci][pt][4 * q + 3]};
+        PP_VM0();                                       // my stores have left (through the builtin: hipcc sees this wait too)
+        PP_BAR();
+        if (wave == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(p.sk_flag + my_wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    // ---- operand fragments of one half step (two K slices): 8 weight + 4 patch ds_read_b128 ----------------------
+    // Address of K slice kk (16-B chunk 2kk + hh of a 128-B row, XOR-swizzled by sw = (row >> 1) & 7):
+    //     row*128 + (((2kk + hh) ^ sw) << 4)  =  [row*128 + ((hh ^ sw) << 4)]  ^  (kk << 5)
+    // so a step needs ONE base per operand row (wa: my weight row, pa[pt]: my two patch rows of this tap) and an XOR per
+    // slice.  Flat tiles: a lane whose tap falls outside the image reads the 128-B ZERO ROW instead (one select per
+    // pixel tile and step, not an AND per fragment register).
+    u32x4 wf[WC][2], pf[2][2];
+    unsigned wa = 0, pa[2] = {0, 0};                    // LDS byte addresses (relative to smem)
+    auto step_addresses = [&](int wslot, int pbuf_, int rowdelta, unsigned tapbits) {
+        const int ln = opaque_lane();
+        const int r32 = ln & 31, hh = ln >> 5;
+        wa = (unsigned)(OFF_W + wslot * WBYTES + grp * (WBYTES / 2) + r32 * 128 + ((hh ^ ((r32 >> 1) & 7)) << 4));
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            // (the tap-(0,0) patch row of my pixel is re-derived here: kept in a register it would be live across the epilogue,
+            // where hipcc spills it -- and re-loads it in every step behind a vmcnt(0))
+            const int i = cw * 64 + pt * 32 + r32;      // tile-local pixel
+            const int row = (TW ? (i >> LGTW) * RS + (i & (TW - 1)) : i) + rowdelta;
+            const unsigned a = (unsigned)(pbuf_ * PBYTES + row * 128 + ((hh ^ ((row >> 1) & 7)) << 4));
+            if constexpr (FLAT) pa[pt] = ((tapmask[pt] >> tapbits) & 1u) ? a : (unsigned)OFF_Z;
+            else pa[pt] = a;
+        }
+    };
+    auto read_frags = [&](int half) {
+        if (!compute) return;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const unsigned kx = (unsigned)((2 * half + k2) << 5);
+#pragma unroll
+            for (int ci = 0; ci < WC; ++ci) wf[ci][k2] = *(const u32x4 *)(smem + ((wa ^ kx) + ci * 4096));
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) pf[pt][k2] = *(const u32x4 *)(smem + (pa[pt] ^ kx));
+        }
+    };
+    // four MFMAs: K slice k2, cout tiles 2*h and 2*h+1, both pixel tiles
+    auto mma_quad = [&](int k2, int h) {
+        if (!compute) return;
+#pragma unroll
+        for (int ci = 2 * h; ci < 2 * h + 2; ++ci)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) MmaPP<DT>::run(wf[ci][k2], pf[pt][k2], acc[ci][pt]);
+    };
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+
+    // =========================== prologue ===========================
+    int cur_item, cc, c1cur;                            // the segment being computed: item, current chunk, end chunk
+    seg(0, cur_item, cc, c1cur);
+    weight_seg();
+    patch_seg();
+    patch_tile(p_item);
+#pragma unroll
+    for (int j = 0; j < kPPPieces; ++j) {
+        prep_patch(j, (unsigned)(p_cc * 128), 0);
+        issue_patch();
+    }
+    weights_begin();                                    // step 0 -> slot 0, all four pieces
+#pragma unroll
+    for (int k = 0; k < 4; ++k) weight_piece(k);
+    if (n_steps > 1) {                                  // step 1 -> slot 1: pieces 0,1 (2,3 follow in M(0, slices 0-1))
+        weights_begin();
+        weight_piece(0);
+        weight_piece(1);
+    }
+    next_patch_chunk();
+    if (wave == 0 && cc == 0) load_bias(cur_item);
+    if (wave == 1 && lane < 8) *(u32x4 *)(smem + OFF_Z + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    PP_VM0();                                           // (see below: hipcc's own scoreboard must be empty when the step loop starts)
+    PP_BAR();
+    setup_item(cur_item);
+    begin_acc(cc);
+    step_addresses(0, 0, 0, 0u);
+    PP_LGKM0();
+    PP_VM0();
+    if (grp == 1) PP_BAR();                             // the stagger: group 1 runs one interval behind group 0
+
+    int kseg = 0, tap = 0, tq = 0, delta = 0, pbuf = 0;
+#ifdef TDRN_PP_STAMP
+    unsigned st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (int g = 0; g < n_steps; ++g) {
+        // ---------------- L(g, slices 0-1): reads ----------------
+#ifdef TDRN_PP_STAMP
+        unsigned long long st_t[9];
+#endif
+        PPT(0);
+        read_frags(0);
+        PP_SB();
+        PP_LGKM0();
+        PPT(1);
+        PP_BAR();
+        PPT(2);
+        // ---------------- M(g, slices 0-1) + pieces 2,3 of step g+1's weights ----------------
+        __builtin_amdgcn_s_setprio(1);
+        mma_quad(0, 0);
+        PP_SB();
+        if (g + 1 < n_steps) weight_piece(2);
+        PP_SB();
+        mma_quad(0, 1);
+        PP_SB();
+        if (g + 1 < n_steps) weight_piece(3);
+        PP_SB();
+        mma_quad(1, 0);
+        mma_quad(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        PPT(3);
+        PP_BAR();
+        PPT(4);
+        // ---------------- L(g, slices 2-3): reads; prepare this tap's piece of the NEXT chunk's patch ----------------
+        read_frags(1);
+        PP_SB();
+        pp_any = false;
+        if (p_k < n_seg && tap < kPPPieces) {
+            if (tap == 0) patch_tile(p_item);
+            prep_patch(tap, (unsigned)(p_cc * 128), p_buf * PBYTES);
+        }
+        // the NEXT segment's bias (if it starts an item) -> the LDS bias slot; this segment read the slot at its start
+        int nx_item = 0, nx_c0 = 1, nx_c1 = 0;
+        const bool last_tap6 = cc == c1cur - 1 && tap == 6 && kseg + 1 < n_seg;
+        if (last_tap6) seg(kseg + 1, nx_item, nx_c0, nx_c1);
+        const bool bias_now = wave == 0 && last_tap6 && nx_c0 == 0;
+        PP_LGKM0();
+        PPT(5);
+        PP_BAR();
+        PPT(6);
+        // ---------------- M(g, slices 2-3) + pieces 0,1 of step g+2's weights (the slot step g just left) + the patch piece ---
+        const bool more = g + 2 < n_steps;
+        __builtin_amdgcn_s_setprio(1);
+        mma_quad(0, 0);
+        PP_SB();
+        if (more) {
+            weights_begin();
+            weight_piece(0);
+        }
+        PP_SB();
+        mma_quad(0, 1);
+        PP_SB();
+        if (more) weight_piece(1);
+        PP_SB();
+        mma_quad(1, 0);
+        PP_SB();
+        issue_patch();
+        if (bias_now) load_bias(nx_item);
+        PP_SB();
+        mma_quad(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        PPT(7);
+        // everything issued BEFORE this segment has landed: all four weight pieces of step g+1 and every older patch piece;
+        // this segment's own pieces (wave-uniform count) stay in flight
+        {
+            const int fly = (TDRN_PP_ABLATE & (1 | 8 | 16)) ? 0 : (more ? 2 : 0) + ((pp_any || bias_now) ? 1 : 0);
+            if (fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (fly == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
+        PPT(8);
+        PP_BAR();
+#ifdef TDRN_PP_STAMP
+        {
+            const unsigned long long t9 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st_acc[k] += (unsigned)(st_t[k + 1] - st_t[k]);
+            st_acc[8] += (unsigned)(t9 - st_t[8]);
+        }
+#endif
+        // ---------------- advance to step g+1 ----------------
+        const bool seg_done = tap == 8 && cc == c1cur - 1;
+        const int dead_buf = pbuf;
+        ++tap;
+        if (++tq == 3) {
+            tq = 0;
+            delta += RS;
+        }
+        if (tap == 9) {
+            tap = 0; tq = 0; delta = 0;
+            pbuf ^= 1;
+            next_patch_chunk();
+            ++cc;
+        }
+        if (!seg_done) step_addresses((g + 1) & 1, pbuf, delta + tq, (unsigned)tap);
+        if (seg_done) {
+            // group 0 waits for group 1's last multiply (one interval), then both groups run their epilogues at the
+            // same time out of the patch buffer that died with this step; group 1 re-creates the stagger behind it
+            if (grp == 0) PP_BAR();
+            if (c1cur == nchunks) epilogue(smem + dead_buf * PBYTES + wave * STRIP);
+            else write_partial();                       // (chained split: the item is finished by my successor)
+            ++kseg;
+            if (kseg < n_seg) {
+                seg(kseg, cur_item, cc, c1cur);
+                setup_item(cur_item);
+                begin_acc(cc);
+                step_addresses((g + 1) & 1, pbuf, 0, 0u);  // (a flat tile's tap masks are the new item's)
+            }
+            PP_LGKM0();
+            // hipcc does not see the LDS-DMA pieces (inline asm), only its own vector-memory operations: the epilogue's stores and
+            // any spill traffic of this rarely executed block.  With one of those still on ITS scoreboard at the loop's back edge
+            // it protects a register it re-uses in the step loop with an `s_waitcnt vmcnt(0)` -- which in hardware drains every
+            // LDS-DMA piece in flight, in every step (measured: +40 % time on the 16x16-tile instantiation).  This builtin wait is
+            // one hipcc DOES see: its scoreboard is empty when the loop is re-entered, and it emits no vmcnt wait inside it.
+            PP_VM0();
+            if (grp == 1) PP_BAR();
+        }
+    }
+    if (grp == 0) PP_BAR();                             // (matches group 1's re-stagger barrier of the last item)
+#ifdef TDRN_PP_STAMP
+    st_acc[9] = (unsigned)(__builtin_amdgcn_s_memtime() - st_begin);
+    if (lane == 0)
+        for (int k = 0; k < 10; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 10 + k] = st_acc[k];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+static int g_pp_override = -1;                          // dev harness / tests: -1 = environment, 0 / 1 = forced
+void conv_pp_force(int v) { g_pp_override = v; }
+int conv_pp_enabled()
+{
+    if (g_pp_override >= 0) return g_pp_override;
+    static int e = -1;
+    if (e < 0) { const char *s = getenv("TDRN_CONV_PP"); e = s ? atoi(s) : 1; }
+    return e;
+}
+
+static int g_pp_sk_override = -1;
+void conv_pp_sk_force(int v) { g_pp_sk_override = v; }
+int conv_pp_sk_enabled()
+{
+    if (g_pp_sk_override >= 0) return g_pp_sk_override;
+    static int e = -1;
+    if (e < 0) { const char *s = getenv("TDRN_CONV_PP_SK"); e = s ? atoi(s) : 1; }
+    return e;
+}
+// scratch of the chained split: 256 flag words + one 256-KiB accumulator slab per workgroup
+size_t conv_pp_sk_bytes() { return 1024 + (size_t)256 * 8 * 32 * 64 * 16; }
+
+// the layers this kernel takes over from conv3x3_patch.hip: 16-bit, >= 2 channel chunks, couts in whole 256-groups
+int pp_conv_supported(const ConvArgs &a)
+{
+    if (!conv_pp_enabled()) return 0;
+    if (a.dtype == TDRN_F32 || a.fuse_x) return 0;
+    if (a.Cin < 128 || a.Cin % 64 || a.Npad % 256) return 0;
+    return patch_conv_supported(a);
+}
+
+int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
+{
+    const int mode = pp_conv_supported(a);
+    if (!mode) return TDRN_E_UNSUPPORTED;
+    // the two pooled layers of a trunk stay on conv3x3_patch.hip: with the pooled epilogue in, this kernel's 256-register
+    // budget spills inside the step loop (the POOL = true instantiation is kept in the source for the day it does not)
+    if (out_pool) return TDRN_E_UNSUPPORTED;
+    PPParams p;
+    p.in = (const char *)a.in; p.w = (const char *)a.w; p.zero = (const char *)a.zero_page; p.bias = a.bias;
+    p.out = (char *)a.out; p.out_pool = (char *)out_pool;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.Cs = (int)a.o_cs; p.Ktot = 9 * a.Cin;
+    p.relu = a.relu;
+    p.M = a.B * a.H * a.W;
+    const int tw = mode > 0 ? mode : 0;
+    if (tw) {
+        p.tiles_x = a.W / tw;
+        p.tiles_per_img = p.tiles_x * (a.H / (256 / tw));
+        p.m_tiles = a.B * p.tiles_per_img;
+    } else {
+        p.tiles_x = 0; p.tiles_per_img = 0;
+        p.m_tiles = cdiv(p.M, 256);
+    }
+    p.n_tiles = a.Npad / 256;
+    p.items = p.m_tiles * p.n_tiles;
+    if (p.items <= 0) return TDRN_OK;
+    // below ~3/4 of a full grid the loader/consumer kernel's smaller (128- / 64-cout) items fill more CUs: measured 2x faster
+    // at 50-100 items, equal at 200 (the two kernels produce the same bits, so the choice may depend on the batch)
+    if (p.items < 192) return TDRN_E_UNSUPPORTED;
+    int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
+    const int cap = a.max_wgs > 0 ? (a.max_wgs / 8) * 8 : 0;
+    if (cap > 0 && grid > cap) grid = cap;
+    // chained split when it shortens the launch: a full grid, more than one item per workgroup, and an item count that does
+    // not divide evenly (otherwise whole items are already balanced); the choice changes no output bit
+    p.sk_slab = nullptr; p.sk_flag = nullptr;
+    if (a.sk_ws && conv_pp_sk_enabled() && grid == 256 && p.items > 256 && p.items % 256 != 0) {
+        p.sk_flag = (unsigned *)a.sk_ws;
+        p.sk_slab = (float *)((char *)a.sk_ws + 1024);
+        TDRN_HIP_TRY(hipMemsetAsync(p.sk_flag, 0, 1024, s));
+    }
+#ifdef TDRN_PP_STAMP
+    // diagnostics build: synchronise after every launch and print the mean cycles per wave and step in each state
+    static unsigned *stamps = nullptr;
+    if (!stamps) TDRN_HIP_TRY(hipMalloc((void **)&stamps, 256 * 8 * 10 * sizeof(unsigned)));
+    TDRN_HIP_TRY(hipMemsetAsync(stamps, 0, 256 * 8 * 10 * sizeof(unsigned), s));
+    p.stamps = stamps;
+    struct Report {
+        const PPParams &p; hipStream_t s; int nchunks;
+        ~Report()
+        {
+            static unsigned host[256 * 8 * 10];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(host, p.stamps, sizeof(host), hipMemcpyDeviceToHost);
+            double c[2][10] = {{0}};
+            int n[2] = {0, 0};
+            for (int b = 0; b < 256; ++b)
+                for (int w = 0; w < 8; ++w) {
+                    const unsigned *v = host + (b * 8 + w) * 10;
+                    if (v[9] == 0) continue;
+                    for (int k = 0; k < 10; ++k) c[w >> 2][k] += v[k];
+                    ++n[w >> 2];
+                }
+            const double steps = (double)((p.items + 255) / 256) * nchunks * 9;
+            for (int g = 0; g < 2; ++g)
+                if (n[g])
+                    fprintf(stderr, "pp_stamp H%d W%d Cin%d Cout%d items%d steps/CU~%.0f group%d cycles/step: L0 %.0f bar %.0f | M0 %.0f bar %.0f | L1 %.0f bar %.0f | M1 %.0f vmcnt %.0f bar %.0f | sum %.0f, kernel total/steps %.0f\n",
+                            p.H, p.W, p.Cin, p.Cout, p.items, steps, g, c[g][0] / n[g] / steps, c[g][1] / n[g] / steps, c[g][2] / n[g] / steps, c[g][3] / n[g] / steps,
+                            c[g][4] / n[g] / steps, c[g][5] / n[g] / steps, c[g][6] / n[g] / steps, c[g][7] / n[g] / steps, c[g][8] / n[g] / steps,
+                            (c[g][0] + c[g][1] + c[g][2] + c[g][3] + c[g][4] + c[g][5] + c[g][6] + c[g][7] + c[g][8]) / n[g] / steps, c[g][9] / n[g] / steps);
+        }
+    } report{p, s, a.Cin / 64};
+#endif
+#define PP_LAUNCH(DT)                                                                                                  \
+    do {                                                                                                               \
+        if (tw == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 0, false>), dim3(grid), dim3(512), 0, s, p);           \
+        else if (tw == 32) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 32, false>), dim3(grid), dim3(512), 0, s, p);   \
+        else hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 16, false>), dim3(grid), dim3(512), 0, s, p);                  \
+    } while (0)
+    if (a.dtype == TDRN_BF16) PP_LAUNCH(bf16_t);
+    else PP_LAUNCH(f16_t);
+#undef PP_LAUNCH
+    return hip_status(hipGetLastError());
+}
+
+}  // namespace tdrn

@@ -40,6 +40,7 @@ struct ConvArgs {
     const float *fuse_x = nullptr, *fuse_w = nullptr, *fuse_b = nullptr;
     int fuse_cout = 0;
     int max_wgs = 0;                // patch kernel: > 0 caps the persistent grid (a multiple of 8), leaving CUs to concurrent lanes
+    void *sk_ws = nullptr;          // conv3x3_pp.hip: scratch of conv_pp_sk_bytes() for the chained split (one launch at a time), or null
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
 int conv_splitk_choice(const ConvArgs &a);          // 1 = no split
@@ -48,6 +49,14 @@ size_t conv_splitk_bytes(const ConvArgs &a, int splits);
 int conv_patch_enabled();                       // TDRN_CONV_PATCH (default 1)
 int patch_conv_supported(const ConvArgs &a);   // 0 = no, 32/16 = 2-D tiles, -1 = flat tiles
 int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s);
+// all-waves-compute ("ping-pong") 3x3/s1/p1 kernel for the 16-bit Cin >= 128, Cout % 256 == 0 layers (conv3x3_pp.hip);
+// launch_conv3x3_patch hands those layers over to it (TDRN_CONV_PP=0 keeps the loader/consumer kernel)
+int pp_conv_supported(const ConvArgs &a);      // 0 = no, else the tile mode of patch_conv_supported
+int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s);
+void conv_pp_force(int v);                      // dev harness: -1 = environment, 0 / 1 = forced
+void conv_pp_sk_force(int v);                   // dev harness: the chained split ("stream-K") of conv3x3_pp.hip on / off
+int conv_pp_sk_enabled();                       // TDRN_CONV_PP_SK (default 1)
+size_t conv_pp_sk_bytes();
 // rows of the packed weight matrix must be padded to a multiple of this
 int conv_n_pad(int cout);
 // channels of every NHWC activation tensor are padded to a multiple of this

@@ -77,6 +77,7 @@ struct tdrn_net {
     std::map<std::string, std::vector<float>> staged;
     std::vector<Op> ops;
     size_t ws_per_sample = 0, blob_bytes = kZeroPageBytes;
+    size_t ws_fixed = 0;                 // batch-independent tail of the workspace: scratch of conv3x3_pp.hip's chained split (main lane)
     int P = 0, fm[4] = {0, 0, 0, 0}, scale_off[5] = {0, 0, 0, 0, 0};
     bool weights_ready = false;
     int profile = 0;                   // 0 off; 1 = events around every launch, single stream; 2 = the same with the side lanes on
@@ -662,6 +663,11 @@ struct tdrn_net {
                 ws_per_sample += lane_bytes[l];
             }
         }
+        // conv3x3_pp.hip's chained split needs a slab per workgroup; only launches on the main lane use it (one at a time)
+        ws_fixed = 0;
+        if (cfg.dtype != TDRN_F32)
+            for (const Op &o : ops)
+                if (o.kind == OP_CONV && o.stat == ST_CONV3 && o.lane == 0 && o.Cin >= 128 && o.Npad % 256 == 0) ws_fixed = align_up(conv_pp_sk_bytes(), 256);
         const char *e = getenv("TDRN_STREAMS");
         if (e && atoi(e) <= 1) use_lanes = false;
         const char *ds = getenv("TDRN_DEFORM_SPLIT");
@@ -874,7 +880,7 @@ struct tdrn_net {
         if (!weights_ready) return TDRN_E_STATE;
         if (!blob || !ws || !io || !io->x || io->batch <= 0) return TDRN_E_ARG;
         const int B = io->batch;
-        if (ws_bytes < ws_per_sample * (size_t)B) return TDRN_E_WORKSPACE;
+        if (ws_bytes < ws_per_sample * (size_t)B + ws_fixed) return TDRN_E_WORKSPACE;
         if (!io->conf) return TDRN_E_ARG;
         const bool is_drn = cfg.model == TDRN_DRN_VGGBN || cfg.model == TDRN_DRN_MOBILENET || cfg.model == TDRN_REFINEDET_VGG;
         const bool has_arm = cfg.model != TDRN_REFINEDET_VGG || cfg.use_refine;
@@ -978,6 +984,7 @@ struct tdrn_net {
                     a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                     a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
                     if (lane != 0) a.max_wgs = side_grid;
+                    if (o.lane == 0 && ws_fixed) a.sk_ws = (char *)ws + ws_per_sample * (size_t)B;
                     if ((int)oi == fuse_first) {
                         a.fuse_x = io->x; a.fuse_w = (const float *)(wb + ops[0].w_off); a.fuse_b = (const float *)(wb + ops[0].b_off);
                         a.fuse_cout = ops[0].Cout;
@@ -1191,7 +1198,7 @@ int tdrn_net_set_param(tdrn_net *net, const char *name, const float *data_host, 
 }
 
 size_t tdrn_net_weight_bytes(const tdrn_net *net) { return net ? net->blob_bytes : 0; }
-size_t tdrn_net_workspace_bytes(const tdrn_net *net, int batch) { return net && batch > 0 ? net->ws_per_sample * (size_t)batch : 0; }
+size_t tdrn_net_workspace_bytes(const tdrn_net *net, int batch) { return net && batch > 0 ? net->ws_per_sample * (size_t)batch + net->ws_fixed : 0; }
 int tdrn_net_num_priors(const tdrn_net *net) { return net ? net->P : TDRN_E_ARG; }
 
 int tdrn_net_pack_weights(tdrn_net *net, void *weights_dev, size_t weights_bytes, void *stream)
