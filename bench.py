@@ -163,7 +163,7 @@ def detection_agreement(size, dtypes, dev, frames=8):
     ref = []
     for i in range(frames):
         arm, _, odm, conf = net_ref.drn_vggbn_forward(sd, x[i:i + 1], 21, True, True)
-        ref.append(np.asarray(orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), scale)[0])[0])     # (C, top_k, 5)
+        ref.append(orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), scale)[0])     # (C, top_k, 5)
     pri_d = torch.from_numpy(pri).to(dev)
 
     def iou(a, b):
