@@ -25,20 +25,22 @@
 //
 // Interval timeline (g = step, one interval = the span between two consecutive barriers; L = load segment,
 // M = 16 MFMAs):
-//     interval 4g+0 : group 0  L(g, K-slices 0-1), prepares a patch piece       group 1  M(g-1, slices 2-3)
-//     interval 4g+1 : group 0  M(g, 0-1) + weight pieces 2,3 of step g+1        group 1  L(g, 0-1)
-//                               + the patch piece of the next chunk
-//     interval 4g+2 : group 0  L(g, 2-3)                                        group 1  M(g, 0-1) + its pieces
-//     interval 4g+3 : group 0  M(g, 2-3) + weight pieces 0,1 of step g+2,       group 1  L(g, 2-3)
-//                               then vmcnt(2): all of step g+1 has landed
-// The LDS-DMA pieces are issued INSIDE the multiply segments, one between two groups of four MFMAs (an MFMA holds a
-// wave's issue for 8 of its 32 cycles: the piece hides in the gap); issued in the load segments (first version: 4-5
-// pieces of ~100+ cycles each next to 12 reads) they stretched those past the 512 cycles of the partner's multiply.
+//     interval 4g+0 : group 0  L(g, K-slices 0-1) + weight pieces 0,1,2 of step g+1     group 1  M(g-1, slices 2-3)
+//     interval 4g+1 : group 0  M(g, 0-1), bare                                          group 1  L(g, 0-1) + its pieces
+//     interval 4g+2 : group 0  L(g, 2-3) + weight piece 3 of step g+1 + the patch       group 1  M(g, 0-1)
+//                               piece of this tap (next chunk's patch)
+//     interval 4g+3 : group 0  M(g, 2-3), then vmcnt([patch] [+bias]):                  group 1  L(g, 2-3) + its pieces
+//                               step g+1's weights have landed
+// An LDS-DMA piece costs the issuing wave ~100 cycles of issue, during which it issues nothing else: inside a multiply segment
+// that is 100 cycles of idle matrix pipe per piece (measured: 3 pieces between the MFMA groups of one segment = +20 % time),
+// inside a load segment it is free as long as the segment stays under the partner's 512 cycles.  So the load segments are kept
+// to the 12 reads + the pieces (3 and 2) and almost no address arithmetic, and the multiply segments are bare.
 // Ordering rules (cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it"): a piece is
 // read only behind the issuing wave's counted vmcnt AND a later barrier; a buffer is re-filled only behind a barrier
 // that every reader passed after an lgkmcnt(0).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -61,19 +63,7 @@ struct PPParams {
     // word per workgroup; null = whole items only
     float *sk_slab;
     unsigned *sk_flag;
-#ifdef TDRN_PP_STAMP
-    unsigned *stamps;              // diagnostics build only: [workgroup][wave][10] cycle sums (s_memtime), see the launcher
-#endif
 };
-
-// In-kernel cycle stamps of a diagnostics build (make EXTRA=-DTDRN_PP_STAMP; never in the product): one s_memtime at every
-// barrier of a step, before and after; the differences are formed once per step, behind the step's last barrier (s_memtime
-// returns through lgkmcnt: reading a stamp earlier would drain the LDS reads of a load segment).
-#ifdef TDRN_PP_STAMP
-#define PPT(k) st_t[k] = __builtin_amdgcn_s_memtime()
-#else
-#define PPT(k) do { } while (0)
-#endif
 
 namespace {
 
@@ -179,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     avail = avail < per_xcd ? avail : per_xcd;
     avail = avail < 0 ? 0 : avail;
     const bool sk = p.sk_slab != nullptr;
-    int n_seg, seg_item0, c0_first = 0, c1_last = nchunks, tail_first = 0, head_last = 0, n_steps;
+    int n_seg, seg_item0, c0_first = 0, c1_last = nchunks, tail_first = 0, head_last = 0;
     if (sk) {
         const int units = avail * nchunks;
         // (units * 32 < 2^31 for any tensor below the 4-GiB limit of patch_conv_supported; 32-bit scalar arithmetic)
@@ -192,12 +182,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
         c1_last = u1 - li * nchunks;
         tail_first = (c1_last != nchunks && n_seg > 1) ? 1 : 0;
         head_last = (c0_first != 0 && n_seg > 1) ? 1 : 0;
-        n_steps = (u1 - u0) * 9;
     } else {
         n_seg = avail > slot ? (avail - slot + istride - 1) / istride : 0;
         if (n_seg == 0) return;                         // (whole workgroup)
         seg_item0 = xcd * per_xcd + slot;
-        n_steps = n_seg * nchunks * 9;
     }
     // segment k of the execution order -> item and chunk range (wave-uniform scalars)
     auto seg = [&](int k, int &item, int &c0, int &c1) {
@@ -285,54 +273,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
             if (pp_ok && !(TDRN_PP_ABLATE & 8)) glds16(p.in, pp_voff, __builtin_amdgcn_readfirstlane(pp_dst));
         }
     };
-    // my group's half of a weight slot: rows grp*128 + (cw + 4k)*8 + lrow, k = 0..3 (the swizzle term is the same for all k).
-    // The four pieces of step s are issued in two multiply segments: pieces 0,1 in M(s-2, slices 2-3) -- right behind the last
-    // reads of the slot's previous tenant, step s-2 -- and pieces 2,3 in M(s-1, slices 0-1); they are waited for at the end
-    // of M(s-1, slices 2-3), >= 1000 cycles after the last of them was issued.
+    // my group's half of a weight slot: rows grp*128 + (cw + 4k)*8 + lrow, k = 0..3 (the swizzle term is the same for all k)
     const unsigned wo = (unsigned)((grp * 128 + cw * 8 + (lane >> 3)) * p.Ktot * ES) + (unsigned)((((lane & 7) ^ ((4 * cw + (lane >> 4)) & 7)) << 4));
     const unsigned wstep = (unsigned)(32u * p.Ktot * ES);
-    // weight stream: the step whose slice is started next is (segment w_k, chunk w_cc < w_c1, tap w_tap)
-    int w_k = 0, w_cc = 0, w_c1 = 0, w_tap = 0, w_slot = 0;
-    unsigned wbase = 0, wk = 0;                         // byte offsets into p.w (32-bit scalars: a 64-bit pointer that hipcc cannot
-                                                        // prove wave-uniform lands in a VGPR pair -- and is spilled)
-    unsigned pend_off = 0;                              // the step whose pieces 0,1 are out and 2,3 are not: source offset and LDS slot half
-    unsigned pend_dst = 0;
-    auto weight_seg = [&]() {                           // position the stream at the start of segment w_k
-        int item, c0;
-        seg(w_k, item, c0, w_c1);
-        w_cc = c0;
-        wbase = (unsigned)__builtin_amdgcn_readfirstlane((item % p.n_tiles) * BN * p.Ktot * ES);
-        wk = (unsigned)(w_cc * 128);
+    // byte offset into p.w of the weight slice of (item, chunk c, tap 0); a tap adds Cin*ES  (32-bit scalars: a 64-bit pointer
+    // that hipcc cannot prove wave-uniform lands in a VGPR pair -- and is spilled)
+    auto weight_off = [&](int item, int c) -> unsigned {
+        return (unsigned)__builtin_amdgcn_readfirstlane((item % p.n_tiles) * BN * p.Ktot * ES + c * 128);
     };
-    auto weights_begin = [&]() {                        // start the next step of the stream: sets pend_*, advances the cursor
-        pend_dst = __builtin_amdgcn_readfirstlane(smem_lds + OFF_W + w_slot * WBYTES + grp * (WBYTES / 2) + cw * 1024);
-        pend_off = __builtin_amdgcn_readfirstlane(wbase + wk);
-        w_slot ^= 1;
-        wk += (unsigned)(p.Cin * ES);
-        if (++w_tap == 9) {
-            w_tap = 0;
-            if (++w_cc == w_c1) {
-                ++w_k;
-                if (w_k < n_seg) weight_seg();
-            } else {
-                wk = (unsigned)(w_cc * 128);
-            }
-        }
-    };
-    auto weight_piece = [&](int k) {
+    // piece k (0..3) of the slice at byte offset `off` -> my group's half of weight slot `slot`
+    auto weight_piece = [&](int k, unsigned off, int slot) {
         unsigned w = wo;
         asm volatile("" : "+v"(w));                     // (or hipcc keeps wo + k*wstep, k = 1..3, live across the loop -- and spills them)
-        if (!(TDRN_PP_ABLATE & 16)) glds16(p.w + pend_off, w + k * wstep, __builtin_amdgcn_readfirstlane(pend_dst + k * 4096));
-    };
-    // patch stream: the chunk being PREFETCHED is (segment p_k, chunk p_cc < p_c1) of item p_item, into buffer p_buf
-    int p_k = 0, p_cc = 0, p_c1 = 0, p_item = 0, p_buf = 0;
-    auto patch_seg = [&]() { seg(p_k, p_item, p_cc, p_c1); };
-    auto next_patch_chunk = [&]() {
-        p_buf ^= 1;
-        if (++p_cc == p_c1) {
-            ++p_k;
-            if (p_k < n_seg) patch_seg();
-        }
+        if (!(TDRN_PP_ABLATE & 16))
+            glds16(p.w + off, w + k * wstep, __builtin_amdgcn_readfirstlane(smem_lds + OFF_W + slot * WBYTES + grp * (WBYTES / 2) + (cw + 4 * k) * 1024));
     };
     auto load_bias = [&](int item) {                    // wave 0: the item's 256 biases = one 1-KiB piece
         glds16((const char *)(p.bias + (item % p.n_tiles) * BN), (unsigned)opaque_lane() * 16u, smem_lds + OFF_B);
@@ -522,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[ci][pt][4 * q + j] = v[j];
                 }
+        PP_VM0();                                       // (through the builtin: hipcc's scoreboard is empty when the step loop resumes)
     };
     auto write_partial = [&]() {
         f32x4 *dst = slab_of(my_wg);
@@ -586,25 +541,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 
     // =========================== prologue ===========================
-    int cur_item, cc, c1cur;                            // the segment being computed: item, current chunk, end chunk
+    // The loop runs chunk by chunk with the nine taps of a chunk UNROLLED: which tap issues which patch piece, where the bias
+    // goes out, when a chunk / a segment ends are compile-time facts of a step; the cursor logic runs once per chunk.  (As a
+    // generic per-step state machine it was ~490 instructions, ~30 branches and ~30 SGPR-spill reads per step -- twice the
+    // issue time of the 32 MFMAs they surround: matrix pipe 44 % busy.)
+    int kseg = 0, cur_item, cc, c1cur;                  // the chunk being computed: segment, item, chunk, end chunk of the segment
     seg(0, cur_item, cc, c1cur);
-    weight_seg();
-    patch_seg();
-    patch_tile(p_item);
+    int n_kseg = 0, n_item = 0, n_cc = 0, n_c1 = 0;     // the chunk after it (n_kseg == n_seg: none)
+    auto next_chunk = [&]() {
+        if (cc + 1 < c1cur) {
+            n_kseg = kseg; n_item = cur_item; n_cc = cc + 1; n_c1 = c1cur;
+        } else {
+            n_kseg = kseg + 1;
+            if (n_kseg < n_seg) seg(n_kseg, n_item, n_cc, n_c1);
+        }
+    };
+    next_chunk();
+    unsigned w_cur = weight_off(cur_item, cc), w_nxt = n_kseg < n_seg ? weight_off(n_item, n_cc) : 0u;
+    int pbuf = 0, cpar = 0;                             // patch buffer of the chunk being computed; parity of its first weight slot
+    patch_tile(cur_item);
 #pragma unroll
     for (int j = 0; j < kPPPieces; ++j) {
-        prep_patch(j, (unsigned)(p_cc * 128), 0);
+        prep_patch(j, (unsigned)(cc * 128), 0);
         issue_patch();
     }
-    weights_begin();                                    // step 0 -> slot 0, all four pieces
+    pp_any = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) weight_piece(k);
-    if (n_steps > 1) {                                  // step 1 -> slot 1: pieces 0,1 (2,3 follow in M(0, slices 0-1))
-        weights_begin();
-        weight_piece(0);
-        weight_piece(1);
-    }
-    next_patch_chunk();
+    for (int k = 0; k < 4; ++k) weight_piece(k, w_cur, 0);     // step 0 -> slot 0
     if (wave == 0 && cc == 0) load_bias(cur_item);
     if (wave == 1 && lane < 8) *(u32x4 *)(smem + OFF_Z + lane * 16) = u32x4{0u, 0u, 0u, 0u};
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -617,142 +580,126 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     PP_VM0();
     if (grp == 1) PP_BAR();                             // the stagger: group 1 runs one interval behind group 0
 
-    int kseg = 0, tap = 0, tq = 0, delta = 0, pbuf = 0;
-#ifdef TDRN_PP_STAMP
-    unsigned st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll 1
-    for (int g = 0; g < n_steps; ++g) {
-        // ---------------- L(g, slices 0-1): reads ----------------
-#ifdef TDRN_PP_STAMP
-        unsigned long long st_t[9];
-#endif
-        PPT(0);
+    const unsigned tapbytes = (unsigned)(p.Cin * ES);
+    // one step: tap T of the current chunk.  `more`: a step follows (its weights are staged here).
+    auto step = [&](auto tapc) {
+        constexpr int T = decltype(tapc)::value;
+        const bool nvalid = n_kseg < n_seg;
+        const bool more = T < 8 || nvalid;
+        const unsigned w_next = T < 8 ? w_cur + (unsigned)(T + 1) * tapbytes : w_nxt;   // the weight slice of the NEXT step
+        const int slot_next = (cpar + T + 1) & 1;
+        // ---------------- L(slices 0-1): reads; weight pieces 0,1,2 of the next step (into the slot the previous step left) ----
+        // (A load segment holds NOTHING but its reads and pieces.)
         read_frags(0);
         PP_SB();
+        if (more) {
+            weight_piece(0, w_next, slot_next);
+            weight_piece(1, w_next, slot_next);
+            weight_piece(2, w_next, slot_next);
+        }
         PP_LGKM0();
-        PPT(1);
         PP_BAR();
-        PPT(2);
-        // ---------------- M(g, slices 0-1) + pieces 2,3 of step g+1's weights ----------------
+        // ---------------- M(slices 0-1) + (between the MFMA groups) the preparation of this tap's patch piece ----------------
         __builtin_amdgcn_s_setprio(1);
         mma_quad(0, 0);
-        PP_SB();
-        if (g + 1 < n_steps) weight_piece(2);
-        PP_SB();
-        mma_quad(0, 1);
-        PP_SB();
-        if (g + 1 < n_steps) weight_piece(3);
-        PP_SB();
-        mma_quad(1, 0);
-        mma_quad(1, 1);
-        __builtin_amdgcn_s_setprio(0);
-        PPT(3);
-        PP_BAR();
-        PPT(4);
-        // ---------------- L(g, slices 2-3): reads; prepare this tap's piece of the NEXT chunk's patch ----------------
-        read_frags(1);
         PP_SB();
         pp_any = false;
-        if (p_k < n_seg && tap < kPPPieces) {
-            if (tap == 0) patch_tile(p_item);
-            prep_patch(tap, (unsigned)(p_cc * 128), p_buf * PBYTES);
+        if constexpr (T < kPPPieces) {
+            if (nvalid) {
+                if constexpr (T == 0) patch_tile(n_item);
+                prep_patch(T, (unsigned)(n_cc * 128), (pbuf ^ 1) * PBYTES);
+            }
         }
-        // the NEXT segment's bias (if it starts an item) -> the LDS bias slot; this segment read the slot at its start
-        int nx_item = 0, nx_c0 = 1, nx_c1 = 0;
-        const bool last_tap6 = cc == c1cur - 1 && tap == 6 && kseg + 1 < n_seg;
-        if (last_tap6) seg(kseg + 1, nx_item, nx_c0, nx_c1);
-        const bool bias_now = wave == 0 && last_tap6 && nx_c0 == 0;
-        PP_LGKM0();
-        PPT(5);
-        PP_BAR();
-        PPT(6);
-        // ---------------- M(g, slices 2-3) + pieces 0,1 of step g+2's weights (the slot step g just left) + the patch piece ---
-        const bool more = g + 2 < n_steps;
-        __builtin_amdgcn_s_setprio(1);
-        mma_quad(0, 0);
-        PP_SB();
-        if (more) {
-            weights_begin();
-            weight_piece(0);
-        }
+        const int fly_patch = pp_any ? 1 : 0;
         PP_SB();
         mma_quad(0, 1);
-        PP_SB();
-        if (more) weight_piece(1);
-        PP_SB();
         mma_quad(1, 0);
-        PP_SB();
-        issue_patch();
-        if (bias_now) load_bias(nx_item);
-        PP_SB();
         mma_quad(1, 1);
         __builtin_amdgcn_s_setprio(0);
-        PPT(7);
-        // everything issued BEFORE this segment has landed: all four weight pieces of step g+1 and every older patch piece;
-        // this segment's own pieces (wave-uniform count) stay in flight
+        if constexpr (T < kPPPieces) PP_LGKM0();        // (the patch piece's zero stores)
+        PP_BAR();
+        // ---------------- L(slices 2-3): reads; weight piece 3 of the next step; the prepared patch piece; the bias ----------
+        read_frags(1);
+        PP_SB();
+        if (more) weight_piece(3, w_next, slot_next);
+        if constexpr (T < kPPPieces) issue_patch();
+        // the NEXT segment's bias (if it starts an item) -> the LDS bias slot; this segment read the slot at its start
+        bool bias_now = false;
+        if constexpr (T == 6) {
+            bias_now = wave == 0 && nvalid && n_kseg != kseg && n_cc == 0;
+            if (bias_now) load_bias(n_item);
+        }
+        PP_LGKM0();
+        PP_BAR();
+        // ---------------- M(slices 2-3) + (between the MFMA groups) the read addresses of the next step ----------------
+        __builtin_amdgcn_s_setprio(1);
+        mma_quad(0, 0);
+        mma_quad(0, 1);
+        PP_SB();
+        if constexpr (T < 8) step_addresses(slot_next, pbuf, ((T + 1) / 3) * RS + (T + 1) % 3, (unsigned)(T + 1));
+        else if (n_kseg == kseg) step_addresses(slot_next, pbuf ^ 1, 0, 0u);     // (a new segment sets them behind its epilogue)
+        PP_SB();
+        mma_quad(1, 0);
+        mma_quad(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        // In-order retirement: `vmcnt(N)` waits for all but the N youngest pieces.  Needed now: the next step's four weight
+        // pieces; issued behind them and free to stay in flight for another step: the patch piece (served from beyond L2) and
+        // the bias.
         {
-            const int fly = (TDRN_PP_ABLATE & (1 | 8 | 16)) ? 0 : (more ? 2 : 0) + ((pp_any || bias_now) ? 1 : 0);
+            const int fly = (TDRN_PP_ABLATE & (1 | 8 | 16)) ? 0 : fly_patch + (bias_now ? 1 : 0);
             if (fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (fly == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else if (fly == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
-        PPT(8);
         PP_BAR();
-#ifdef TDRN_PP_STAMP
-        {
-            const unsigned long long t9 = __builtin_amdgcn_s_memtime();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) st_acc[k] += (unsigned)(st_t[k + 1] - st_t[k]);
-            st_acc[8] += (unsigned)(t9 - st_t[8]);
-        }
-#endif
-        // ---------------- advance to step g+1 ----------------
-        const bool seg_done = tap == 8 && cc == c1cur - 1;
+    };
+#pragma unroll 1
+    for (;;) {
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+        // ---------------- the chunk is done ----------------
+        const bool seg_done = n_kseg != kseg;
         const int dead_buf = pbuf;
-        ++tap;
-        if (++tq == 3) {
-            tq = 0;
-            delta += RS;
+        const int c1_done = c1cur;
+        pbuf ^= 1;
+        cpar ^= 1;
+        kseg = n_kseg; cur_item = n_item; cc = n_cc; c1cur = n_c1;
+        if (kseg < n_seg) {
+            w_cur = w_nxt;
+            next_chunk();
+            w_nxt = n_kseg < n_seg ? weight_off(n_item, n_cc) : 0u;
         }
-        if (tap == 9) {
-            tap = 0; tq = 0; delta = 0;
-            pbuf ^= 1;
-            next_patch_chunk();
-            ++cc;
-        }
-        if (!seg_done) step_addresses((g + 1) & 1, pbuf, delta + tq, (unsigned)tap);
         if (seg_done) {
             // group 0 waits for group 1's last multiply (one interval), then both groups run their epilogues at the
             // same time out of the patch buffer that died with this step; group 1 re-creates the stagger behind it
             if (grp == 0) PP_BAR();
-            if (c1cur == nchunks) epilogue(smem + dead_buf * PBYTES + wave * STRIP);
+            if (c1_done == nchunks) epilogue(smem + dead_buf * PBYTES + wave * STRIP);
             else write_partial();                       // (chained split: the item is finished by my successor)
-            ++kseg;
             if (kseg < n_seg) {
-                seg(kseg, cur_item, cc, c1cur);
                 setup_item(cur_item);
                 begin_acc(cc);
-                step_addresses((g + 1) & 1, pbuf, 0, 0u);  // (a flat tile's tap masks are the new item's)
+                step_addresses(cpar, pbuf, 0, 0u);     // (a flat tile's tap masks are the new item's)
             }
             PP_LGKM0();
-            // hipcc does not see the LDS-DMA pieces (inline asm), only its own vector-memory operations: the epilogue's stores and
-            // any spill traffic of this rarely executed block.  With one of those still on ITS scoreboard at the loop's back edge
-            // it protects a register it re-uses in the step loop with an `s_waitcnt vmcnt(0)` -- which in hardware drains every
-            // LDS-DMA piece in flight, in every step (measured: +40 % time on the 16x16-tile instantiation).  This builtin wait is
-            // one hipcc DOES see: its scoreboard is empty when the loop is re-entered, and it emits no vmcnt wait inside it.
-            PP_VM0();
+            // (No vmcnt wait here: the epilogue's stores drain under the next segment's first step -- waiting for them cost
+            // ~5 us per item, 14 % of a 36-step item.  hipcc's own scoreboard holds only STORES at this point, which it never
+            // waits for; the one path with loads, begin_acc's slab read, ends in a builtin vmcnt(0) of its own.  Why that
+            // matters: hipcc does not see the LDS-DMA pieces (inline asm); with a LOAD of its own -- a spill re-load, the slab
+            // read -- still on its scoreboard at the loop's back edge it protects the register with an `s_waitcnt vmcnt(0)`
+            // inside the step loop, which in hardware drains every piece in flight, every step: +40 % time when it happened.)
             if (grp == 1) PP_BAR();
+            if (kseg >= n_seg) break;
         }
     }
     if (grp == 0) PP_BAR();                             // (matches group 1's re-stagger barrier of the last item)
-#ifdef TDRN_PP_STAMP
-    st_acc[9] = (unsigned)(__builtin_amdgcn_s_memtime() - st_begin);
-    if (lane == 0)
-        for (int k = 0; k < 10; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 10 + k] = st_acc[k];
-#endif
+
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -826,38 +773,6 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
         p.sk_slab = (float *)((char *)a.sk_ws + 1024);
         TDRN_HIP_TRY(hipMemsetAsync(p.sk_flag, 0, 1024, s));
     }
-#ifdef TDRN_PP_STAMP
-    // diagnostics build: synchronise after every launch and print the mean cycles per wave and step in each state
-    static unsigned *stamps = nullptr;
-    if (!stamps) TDRN_HIP_TRY(hipMalloc((void **)&stamps, 256 * 8 * 10 * sizeof(unsigned)));
-    TDRN_HIP_TRY(hipMemsetAsync(stamps, 0, 256 * 8 * 10 * sizeof(unsigned), s));
-    p.stamps = stamps;
-    struct Report {
-        const PPParams &p; hipStream_t s; int nchunks;
-        ~Report()
-        {
-            static unsigned host[256 * 8 * 10];
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(host, p.stamps, sizeof(host), hipMemcpyDeviceToHost);
-            double c[2][10] = {{0}};
-            int n[2] = {0, 0};
-            for (int b = 0; b < 256; ++b)
-                for (int w = 0; w < 8; ++w) {
-                    const unsigned *v = host + (b * 8 + w) * 10;
-                    if (v[9] == 0) continue;
-                    for (int k = 0; k < 10; ++k) c[w >> 2][k] += v[k];
-                    ++n[w >> 2];
-                }
-            const double steps = (double)((p.items + 255) / 256) * nchunks * 9;
-            for (int g = 0; g < 2; ++g)
-                if (n[g])
-                    fprintf(stderr, "pp_stamp H%d W%d Cin%d Cout%d items%d steps/CU~%.0f group%d cycles/step: L0 %.0f bar %.0f | M0 %.0f bar %.0f | L1 %.0f bar %.0f | M1 %.0f vmcnt %.0f bar %.0f | sum %.0f, kernel total/steps %.0f\n",
-                            p.H, p.W, p.Cin, p.Cout, p.items, steps, g, c[g][0] / n[g] / steps, c[g][1] / n[g] / steps, c[g][2] / n[g] / steps, c[g][3] / n[g] / steps,
-                            c[g][4] / n[g] / steps, c[g][5] / n[g] / steps, c[g][6] / n[g] / steps, c[g][7] / n[g] / steps, c[g][8] / n[g] / steps,
-                            (c[g][0] + c[g][1] + c[g][2] + c[g][3] + c[g][4] + c[g][5] + c[g][6] + c[g][7] + c[g][8]) / n[g] / steps, c[g][9] / n[g] / steps);
-        }
-    } report{p, s, a.Cin / 64};
-#endif
 #define PP_LAUNCH(DT)                                                                                                  \
     do {                                                                                                               \
         if (tw == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 0, false>), dim3(grid), dim3(512), 0, s, p);           \

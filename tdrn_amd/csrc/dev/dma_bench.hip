@@ -94,6 +94,69 @@ template <int MFMA, int NBAR> __global__ __launch_bounds__(512, 2) void pp_skele
     for (int i = 0; i < 8; ++i) t += acc[i][lane & 15];
     if (t == 12345.f) sink[threadIdx.x] = t + smem[threadIdx.x];
 }
+// schedule B of conv3x3_pp: load segments = 12 ds_read_b128 (+ 3 / 2 pieces), multiply segments = 16 bare MFMAs
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int DMA, int READS> __global__ __launch_bounds__(512, 2) void pp_skeleton2(const P p, float *sink)
+{
+    __shared__ __attribute__((aligned(16))) char smem[150 * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lane_off = (unsigned)(lane >> 3) * p.row_stride + (unsigned)(lane & 7) * 16u;
+    const unsigned piece_bytes = 8u * p.row_stride;
+    const char *base = p.src;
+    unsigned cur = (unsigned)wave * 5u * piece_bytes;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    u32x4 fr[12];
+    const int r32 = lane & 31, hh = lane >> 5;
+    const unsigned ra = (unsigned)(88 * 1024 + grp * 16384 + r32 * 128 + ((hh ^ ((r32 >> 1) & 7)) << 4));   // "weights"
+    const unsigned rp = (unsigned)((wave & 3) * 64 * 128 + r32 * 128 + ((hh ^ ((r32 >> 1) & 7)) << 4));      // "patch"
+#define BAR2() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RD(h) do { if (READS) { for (int k2 = 0; k2 < 2; ++k2) { const unsigned kx = (unsigned)((2 * (h) + k2) << 5); \
+        for (int ci = 0; ci < 4; ++ci) fr[k2 * 6 + ci] = *(const u32x4 *)(smem + ((ra ^ kx) + ci * 4096)); \
+        fr[k2 * 6 + 4] = *(const u32x4 *)(smem + (rp ^ kx)); fr[k2 * 6 + 5] = *(const u32x4 *)(smem + ((rp + 4096) ^ kx)); } } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PC(j) do { if (DMA) { const int slot = 88 * 1024 + ((i & 1) * 32768) + grp * 16384 + ((wave & 3) + 4 * ((j) & 3)) * 1024; piece<2>(base, cur + lane_off, __builtin_amdgcn_readfirstlane(lds0 + slot), smem + slot); cur += piece_bytes; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MM16() do { __builtin_amdgcn_s_setprio(1); for (int k2 = 0; k2 < 2; ++k2) for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(i16x8, fr[k2 * 6 + (q >> 1)]), __builtin_bit_cast(i16x8, fr[k2 * 6 + 4 + (q & 1)]), acc[q], 0, 0, 0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+    for (int j = 0; j < 12; ++j) fr[j] = u32x4{(unsigned)lane * 0x01010101u + j, 0x3c003c00u, 0x3c003c00u + j, 0x40004000u};
+    if (grp == 1) BAR2();
+    for (int i = 0; i < p.iters; ++i) {
+        RD(0); PC(0); PC(1); PC(2);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        BAR2();
+        MM16();
+        BAR2();
+        RD(1); PC(3); PC(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        BAR2();
+        MM16();
+        if (cur + 6u * piece_bytes > p.table_bytes) cur = (unsigned)wave * 5u * piece_bytes;
+        if (DMA) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        BAR2();
+    }
+    if (grp == 0) BAR2();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float t = 0;
+    for (int i = 0; i < 8; ++i) t += acc[i][lane & 15];
+    if (t == 12345.f) sink[threadIdx.x] = t + smem[threadIdx.x];
+}
+template <int DMA, int READS> static void run_skel2(const char *name, const char *buf, unsigned row_stride, unsigned table_bytes, float *sink)
+{
+    P p{buf, row_stride, table_bytes, 0, 2000};
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((pp_skeleton2<DMA, READS>), dim3(256), dim3(512), 0, 0, p, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((pp_skeleton2<DMA, READS>), dim3(256), dim3(512), 0, 0, p, sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-64s %8.1f us  %6.0f ns/step (MFMA floor at 2.4 GHz: 853)\n", name, ms * 1e3, ms * 1e6 / p.iters);
+    fflush(stdout);
+}
+
 template <int MFMA, int NBAR> static void run_skel(const char *name, const char *buf, unsigned row_stride, unsigned table_bytes, float *sink)
 {
     P p{buf, row_stride, table_bytes, 0, 2000};
@@ -156,6 +219,10 @@ int main()
     run<2, 1, 8>("asm      8x128B stride 512 private-4MB vmcnt(8)", buf, 512, 4000000, 4u << 20);
     float *sink;
     CK(hipMalloc((void **)&sink, 4096));
+    run_skel2<0, 0>("skeleton2: MFMA + barriers only", buf, 4608, 1179648, sink);
+    run_skel2<1, 0>("skeleton2: + 5 DMA pieces in the load segments", buf, 4608, 1179648, sink);
+    run_skel2<0, 1>("skeleton2: + 24 ds_read_b128 per wave and step", buf, 4608, 1179648, sink);
+    run_skel2<1, 1>("skeleton2: + both", buf, 4608, 1179648, sink);
     run_skel<0, 1>("skeleton: barriers, no MFMA, stride 4608 shared", buf, 4608, 1179648, sink);
     run_skel<0, 0>("skeleton: NO barriers, no MFMA, stride 4608 shared", buf, 4608, 1179648, sink);
     run_skel<1, 1>("skeleton: barriers + 32 MFMA/step/wave, stride 4608 shared", buf, 4608, 1179648, sink);
