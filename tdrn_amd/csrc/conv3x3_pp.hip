@@ -588,20 +588,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
         const bool more = T < 8 || nvalid;
         const unsigned w_next = T < 8 ? w_cur + (unsigned)(T + 1) * tapbytes : w_nxt;   // the weight slice of the NEXT step
         const int slot_next = (cpar + T + 1) & 1;
-        // ---------------- L(slices 0-1): reads; weight pieces 0,1,2 of the next step (into the slot the previous step left) ----
-        // (A load segment holds NOTHING but its reads and pieces.)
+        // ---------------- L(slices 0-1): reads; the four weight pieces of the next step (into the slot the previous step left) ----
         read_frags(0);
         PP_SB();
         if (more) {
             weight_piece(0, w_next, slot_next);
             weight_piece(1, w_next, slot_next);
             weight_piece(2, w_next, slot_next);
+            weight_piece(3, w_next, slot_next);
         }
         PP_LGKM0();
         PP_BAR();
-        // ---------------- M(slices 0-1) + (between the MFMA groups) the preparation of this tap's patch piece ----------------
+        // ---------------- M(slices 0-1): the 16 MFMAs, nothing else ----------------
         __builtin_amdgcn_s_setprio(1);
         mma_quad(0, 0);
+        mma_quad(0, 1);
+        mma_quad(1, 0);
+        mma_quad(1, 1);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---------------- L(slices 2-3): reads; this tap's piece of the NEXT chunk's patch (prepared here); the bias ----------
+        read_frags(1);
         PP_SB();
         pp_any = false;
         if constexpr (T < kPPPieces) {
@@ -611,17 +618,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
             }
         }
         const int fly_patch = pp_any ? 1 : 0;
-        PP_SB();
-        mma_quad(0, 1);
-        mma_quad(1, 0);
-        mma_quad(1, 1);
-        __builtin_amdgcn_s_setprio(0);
-        if constexpr (T < kPPPieces) PP_LGKM0();        // (the patch piece's zero stores)
-        PP_BAR();
-        // ---------------- L(slices 2-3): reads; weight piece 3 of the next step; the prepared patch piece; the bias ----------
-        read_frags(1);
-        PP_SB();
-        if (more) weight_piece(3, w_next, slot_next);
         if constexpr (T < kPPPieces) issue_patch();
         // the NEXT segment's bias (if it starts an item) -> the LDS bias slot; this segment read the slot at its start
         bool bias_now = false;
