@@ -594,16 +594,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
         if (more) {
             weight_piece(0, w_next, slot_next);
             weight_piece(1, w_next, slot_next);
-            weight_piece(2, w_next, slot_next);
-            weight_piece(3, w_next, slot_next);
         }
         PP_LGKM0();
         PP_BAR();
-        // ---------------- M(slices 0-1): the 16 MFMAs, nothing else ----------------
+        // ---------------- M(slices 0-1): the 16 MFMAs + the other two weight pieces between the groups ----------------
         __builtin_amdgcn_s_setprio(1);
         mma_quad(0, 0);
+        PP_SB();
+        if (more) weight_piece(2, w_next, slot_next);
+        PP_SB();
         mma_quad(0, 1);
         mma_quad(1, 0);
+        PP_SB();
+        if (more) weight_piece(3, w_next, slot_next);
+        PP_SB();
         mma_quad(1, 1);
         __builtin_amdgcn_s_setprio(0);
         PP_BAR();
@@ -726,7 +730,9 @@ int pp_conv_supported(const ConvArgs &a)
 {
     if (!conv_pp_enabled()) return 0;
     if (a.dtype == TDRN_F32 || a.fuse_x) return 0;
-    if (a.Cin < 128 || a.Cin % 64 || a.Npad % 256) return 0;
+    // (Cin = 128 -- two chunks, 18 steps per item -- stays with conv3x3_patch.hip: the per-item cost of this kernel, drain +
+    // epilogue + re-stagger, weighs 10 % there: 125 vs 116 us on conv3_1 in the net)
+    if (a.Cin < 256 || a.Cin % 64 || a.Npad % 256) return 0;
     return patch_conv_supported(a);
 }
 

@@ -667,7 +667,7 @@ struct tdrn_net {
         ws_fixed = 0;
         if (cfg.dtype != TDRN_F32)
             for (const Op &o : ops)
-                if (o.kind == OP_CONV && o.stat == ST_CONV3 && o.lane == 0 && o.Cin >= 128 && o.Npad % 256 == 0) ws_fixed = align_up(conv_pp_sk_bytes(), 256);
+                if (o.kind == OP_CONV && o.stat == ST_CONV3 && o.lane == 0 && o.Cin >= 256 && o.Npad % 256 == 0) ws_fixed = align_up(conv_pp_sk_bytes(), 256);
         const char *e = getenv("TDRN_STREAMS");
         if (e && atoi(e) <= 1) use_lanes = false;
         const char *ds = getenv("TDRN_DEFORM_SPLIT");
