@@ -386,4 +386,184 @@ int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_
 
 int launch_deform(const DeformArgs &a, hipStream_t s) { return launch_deform_multi(&a, 1, s, 0); }
 
+// =============================================================================================
+// Transform, then sample (16-bit plans, one deformable group, Cout <= 80 -- the ODM heads).
+//
+// The op is linear in the sampled columns and has FEWER outputs (75: 12 loc + 63 conf) than inputs (256):
+//     out[p][co] = sum_tap sum_c W[co][tap][c] * ( sum_k w_k(p,tap) * X[corner_k(p,tap)][c] )
+//                = sum_tap sum_k w_k(p,tap) * Y[corner_k(p,tap)][tap][co],      Y[q][tap][co] = sum_c W[co][tap][c] * X[q][c]
+// Y is ONE plain 1x1 GEMM per pyramid level (conv_igemm.hip: 256 -> 34 taps x 80 columns, the same FLOPs as the fused
+// kernel's, at dense-GEMM rate, fp32 accumulation, rounded once to the net dtype); the bilinear blend then gathers 160-byte
+// rows instead of 512-byte ones and blends 75 values per corner instead of 256 -- 3.4x less of exactly the two things that
+// bound deform_gemm_kernel above (gathered bytes, vector-ALU blend: profiles/r02_final).  The sampling rule -- which taps
+// are rejected, the (H-1, H) clamp, fp32 offsets and weights -- is the same code as tap_params() there
+// (deform_conv_cuda_kernel.cu:15-51, 189-203); no atomics, no zero-fill: one wave owns one output pixel and both branches.
+// Where the rounding sits differs from the fused kernel (Y is rounded to 16 bits, there the blended columns are); the fp32
+// mode and the fp32 C-ABI entry keep the fused kernel.
+// =============================================================================================
+struct SampleBranchP {
+    const float *off;              // offsets of this branch: [pixel][off_stride], 2 floats per tap (dh, dw)
+    int off_stride, kh, kw, pad_h, pad_w, dil_h, dil_w, col0;   // col0: first Y column block (tap index) of the branch
+};
+struct SampleParams {
+    const char *y;                 // [B*H*W][ycs] DT: tap t's 80 columns at t*80
+    SampleBranchP br[2];
+    int n_branches, n_taps;
+    int M, H, W, ycs, Cout, split;
+    float *out0, *out1;
+    long long o0_bs, o0_ps, o1_bs, o1_ps;
+};
+struct SampleMulti {
+    SampleParams p[4];
+    int block_start[5];
+    int n;
+};
+constexpr int kSampleCols = 80;    // Y columns per tap (75 used)
+
+template <typename DT>
+__global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp)
+{
+    int prob = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < mp.n && (int)blockIdx.x >= mp.block_start[i]) prob = i;
+    const SampleParams &p = mp.p[prob];
+    constexpr int MAXR = 34 * 4;                        // corner rows of one output pixel (9 + 25 taps)
+    __shared__ unsigned s_off[4][MAXR + 8];             // per wave: byte offset of a corner's Y row (incl. the tap's columns)
+    __shared__ float s_w[4][MAXR + 8];                  // ... and its bilinear weight (0: tap rejected)
+    __shared__ float s_red[4][6][kSampleCols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = ((int)blockIdx.x - mp.block_start[prob]) * 4 + wave;     // one wave = one output pixel (stride 1: Ho = H)
+    if (m >= p.M) return;
+    const int HW = p.H * p.W;
+    const int b = m / HW, rem = m - b * HW, ho = rem / p.W, wo = rem - ho * p.W;
+    const int nrows = p.n_taps * 4;
+    if (lane < p.n_taps) {
+        const int brn = (p.n_branches == 2 && lane >= p.br[0].kh * p.br[0].kw) ? 1 : 0;
+        const SampleBranchP &B = p.br[brn];
+        const int tl = lane - (brn ? p.br[0].kh * p.br[0].kw : 0);
+        const int ti = tl / B.kw, tj = tl - ti * B.kw;
+        const float *op = B.off + (size_t)m * B.off_stride + 2 * tl;
+        const float offset_h = op[0], offset_w = op[1];
+        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+        int q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+        const int h_in = ho - B.pad_h, w_in = wo - B.pad_w;
+        const float h_im = (float)(h_in + ti * B.dil_h) + offset_h;
+        const float w_im = (float)(w_in + tj * B.dil_w) + offset_w;
+        if (h_im >= 0.f && w_im >= 0.f && h_im < (float)p.H && w_im < (float)p.W) {
+            float h = (float)(ti * B.dil_h) + offset_h;     // map_h, relative to h_in
+            float w = (float)(tj * B.dil_w) + offset_w;
+            const int height = p.H - h_in, width = p.W - w_in;
+            int h_low = (int)floorf(h), w_low = (int)floorf(w), h_high, w_high;
+            if (h_low >= height - 1) { h_high = h_low = height - 1; h = (float)h_low; } else { h_high = h_low + 1; }
+            if (w_low >= width - 1) { w_high = w_low = width - 1; w = (float)w_low; } else { w_high = w_low + 1; }
+            const float lh = h - (float)h_low, lw = w - (float)w_low;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            w1 = hh * hw; w2 = hh * lw; w3 = lh * hw; w4 = lh * lw;
+            const int r0 = min(max(h_in + h_low, 0), p.H - 1), r1 = min(max(h_in + h_high, 0), p.H - 1);
+            const int c0 = min(max(w_in + w_low, 0), p.W - 1), c1 = min(max(w_in + w_high, 0), p.W - 1);
+            q1 = r0 * p.W + c0; q2 = r0 * p.W + c1; q3 = r1 * p.W + c0; q4 = r1 * p.W + c1;
+        }
+        const unsigned colb = (unsigned)((B.col0 + tl) * kSampleCols * 2);
+        const unsigned rowb = (unsigned)(p.ycs * 2);
+        const unsigned img = (unsigned)(b * HW);
+        s_off[wave][4 * lane + 0] = (img + q1) * rowb + colb; s_w[wave][4 * lane + 0] = w1;
+        s_off[wave][4 * lane + 1] = (img + q2) * rowb + colb; s_w[wave][4 * lane + 1] = w2;
+        s_off[wave][4 * lane + 2] = (img + q3) * rowb + colb; s_w[wave][4 * lane + 2] = w3;
+        s_off[wave][4 * lane + 3] = (img + q4) * rowb + colb; s_w[wave][4 * lane + 3] = w4;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // lanes 10j + c (j = 0..5, c = 0..9): corner row 6i + j, 16-byte column chunk c; lanes 60..63 idle
+    const int j = lane / 10, c = lane - 10 * j;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lane < 60) {
+        // branch-free batches of six independent 16-byte loads (rows past the end re-read the last row with weight 0)
+        const int nb = (nrows + 35) / 36;
+        for (int ib = 0; ib < nb; ++ib) {
+            u32x4 raw[6];
+            float wgt[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int r = 6 * (6 * ib + u) + j;
+                const int rc = r < nrows ? r : nrows - 1;
+                wgt[u] = r < nrows ? s_w[wave][rc] : 0.f;
+                raw[u] = *(const u32x4 *)(p.y + s_off[wave][rc] + c * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                float v[8];
+                unpack16<DT>(raw[u], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt[u], v[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_red[wave][j][c * 8 + e] = acc[e];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // columns 0..79: a fixed-order sum over the six row groups (deterministic)
+    for (int co = lane; co < p.Cout; co += 64) {
+        float v = s_red[wave][0][co];
+#pragma unroll
+        for (int jj = 1; jj < 6; ++jj) v += s_red[wave][jj][co];
+        float *dst = co < p.split ? p.out0 + b * p.o0_bs + rem * p.o0_ps + co : p.out1 + b * p.o1_bs + rem * p.o1_ps + (co - p.split);
+        *dst = v;
+    }
+}
+
+// the fast path takes: 16-bit, stride 1, one deformable group, at most two branches with at most 34 taps together, Cout <= 80
+int deform_sample_supported(const DeformArgs &a)
+{
+    if (a.dtype == TDRN_F32 || a.n_branches < 1 || a.n_branches > 2 || a.Cout > kSampleCols || a.Ho != a.H || a.Wo != a.W) return 0;
+    int taps = 0;
+    for (int i = 0; i < a.n_branches; ++i) {
+        const DeformBranch &b = a.br[i];
+        if (b.G != 1 || b.stride != 1 || (b.stride_w >= 1 && b.stride_w != 1)) return 0;
+        taps += b.kh * b.kw;
+    }
+    return taps <= 34 ? taps : 0;
+}
+int deform_sample_cols(int taps) { return (int)align_up((size_t)taps * kSampleCols, 128); }
+
+// y[i]: the level's Y tensor ([B*H*W][ycs[i]], net dtype), computed by the caller's 1x1 GEMM with the branches' taps in order
+int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s)
+{
+    if (!args || n < 1 || n > 4) return TDRN_E_ARG;
+    SampleMulti mp;
+    mp.n = 0;
+    mp.block_start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const DeformArgs &a = args[i];
+        const int taps = deform_sample_supported(a);
+        if (!taps || a.dtype != args[0].dtype) return TDRN_E_UNSUPPORTED;
+        if ((long long)a.B * a.H * a.W * ycs[i] * 2 >= (1ll << 32)) return TDRN_E_UNSUPPORTED;     // 32-bit byte offsets into Y
+        SampleParams p;
+        p.y = (const char *)y[i];
+        p.n_branches = a.n_branches; p.n_taps = taps;
+        int col0 = 0;
+        for (int k = 0; k < a.n_branches; ++k) {
+            const DeformBranch &b = a.br[k];
+            p.br[k] = SampleBranchP{b.off, b.off_stride, b.kh, b.kw, b.pad, b.pad_w < 0 ? b.pad : b.pad_w, b.dil, b.dil_w < 1 ? b.dil : b.dil_w, col0};
+            col0 += b.kh * b.kw;
+        }
+        if (a.n_branches == 1) p.br[1] = p.br[0];
+        p.M = a.B * a.H * a.W; p.H = a.H; p.W = a.W; p.ycs = ycs[i]; p.Cout = a.Cout;
+        p.split = a.split > a.Cout ? a.Cout : a.split;
+        p.out0 = a.out0; p.out1 = a.out1;
+        p.o0_bs = a.o0_bs; p.o0_ps = a.o0_ps; p.o1_bs = a.o1_bs; p.o1_ps = a.o1_ps;
+        if (p.M <= 0) continue;
+        mp.p[mp.n] = p;
+        mp.block_start[mp.n + 1] = mp.block_start[mp.n] + cdiv(p.M, 4);
+        ++mp.n;
+    }
+    if (mp.n == 0) return TDRN_OK;
+    for (int i = mp.n; i < 4; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
+    dim3 grid((unsigned)mp.block_start[mp.n]);
+    if (args[0].dtype == TDRN_BF16) hipLaunchKernelGGL((deform_sample_kernel<bf16_t>), grid, dim3(256), 0, s, mp);
+    else hipLaunchKernelGGL((deform_sample_kernel<f16_t>), grid, dim3(256), 0, s, mp);
+    return hip_status(hipGetLastError());
+}
+
 }  // namespace tdrn

@@ -132,6 +132,11 @@ int launch_deform(const DeformArgs &a, hipStream_t s);
 // split_branches = 1: two-branch problems run as two work items that atomicAdd into PRE-ZEROED outputs
 int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_branches);
 int deform_n_pad(int cout);
+// transform-then-sample path of the 16-bit one-group heads (deform.hip): the caller computes Y = 1x1 GEMM of the input with the
+// per-tap weight slabs ([taps][80 columns] per pixel, deform_sample_cols(taps) channels), this launch blends the corners
+int deform_sample_supported(const DeformArgs &a);      // 0 = no, else the number of taps of all branches
+int deform_sample_cols(int taps);
+int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Detect (detect.hip)

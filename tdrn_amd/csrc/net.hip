@@ -52,6 +52,8 @@ struct Op {
     int loc_src = OUT_ARM_LOC;                            // OP_OFFSET input: ARM loc view or a ref_loc tensor
     std::string w, b, bn, w2, b2;                          // parameter names (w2/b2: second source)
     size_t w_off = 0, b_off = 0, w2_off = 0;               // blob offsets
+    int y_t = -1, y_cols = 0;                              // deform, transform-then-sample plans: the Y tensor (per-tap partial outputs)
+    size_t wt_off = 0, bt_off = 0;                         // ... its 1x1 GEMM weights [y_cols][Cin] and zero bias
     double flops = 0, bytes = 0;                           // algorithmic, per sample
     int stat = 0;
     int lane = 0;                                          // HIP stream lane (0 = the caller's stream)
@@ -332,6 +334,17 @@ struct tdrn_net {
         o.hw = ti.H * 65536 + ti.W;
         o.flops = 2.0 * ti.H * ti.W * o.Cout * taps * ti.C;
         o.bytes = (double)ti.H * ti.W * (ti.Cpad * es + (o.Cout + 2 * taps * G) * 4);
+        // 16-bit plans, one deformable group: transform (1x1 GEMM into per-tap partial outputs), then sample (deform.hip);
+        // TDRN_DEFORM_TS=0 keeps the fused gather kernel
+        {
+            const char *e = getenv("TDRN_DEFORM_TS");
+            if (!(e && atoi(e) == 0) && cfg.dtype != TDRN_F32 && G == 1 && o.Cout <= 80 && (int)taps <= 34) {
+                o.y_cols = deform_sample_cols((int)taps);
+                o.y_t = T(o.y_cols, ti.H, ti.W);
+                o.wt_off = blob((size_t)o.y_cols * o.Cin * es);
+                o.bt_off = blob((size_t)o.y_cols * 4);
+            }
+        }
         push(o);
     }
 
@@ -850,6 +863,24 @@ struct tdrn_net {
                 case OP_DEFORM: {
                     const Tensor &ti = tensors[o.in];
                     const int nc3 = 3 * cfg.num_classes;
+                    if (o.y_t >= 0) {        // rows (tap, column) of the 1x1 GEMM: tap-major over the branches, 80 columns per tap
+                        char *dt = host.data() + o.wt_off;
+                        int tap0 = 0;
+                        for (int br = 0; br < o.n_branches; ++br) {
+                            const std::string &ln = br ? o.w2 : o.w, &cn = br ? o.b2 : o.b;
+                            const auto *wl = get(ln + ".weight"), *wc = get(cn + ".weight");
+                            if (!wl || !wc) return TDRN_E_PARAM;
+                            const int k = br ? o.k2 : o.k, taps = k * k;
+                            for (int t = 0; t < taps; ++t)
+                                for (int co = 0; co < 12 + nc3; ++co) {
+                                    const std::vector<float> &src = co < 12 ? *wl : *wc;
+                                    const int cs = co < 12 ? co : co - 12;
+                                    for (int ci = 0; ci < ti.C; ++ci)
+                                        put_elem(dt, ((size_t)(tap0 + t) * 80 + co) * o.Cin + ci, src[((size_t)cs * ti.C + ci) * taps + t]);
+                                }
+                            tap0 += taps;
+                        }
+                    }
                     for (int br = 0; br < o.n_branches; ++br) {
                         const std::string &ln = br ? o.w2 : o.w, &cn = br ? o.b2 : o.b;
                         const auto *wl = get(ln + ".weight"), *wc = get(cn + ".weight");
@@ -932,7 +963,7 @@ struct tdrn_net {
             int n_deform_groups = 0;
             for (size_t k = 0; k < ops.size(); ++k)
                 if (ops[k].kind == OP_DEFORM) {
-                    if (ops[k].n_branches == 2 && !dsplit) dsplit = &ops[k];
+                    if (ops[k].n_branches == 2 && ops[k].y_t < 0 && !dsplit) dsplit = &ops[k];     // (the transform-then-sample path stores, no atomics)
                     if (k == 0 || ops[k - 1].kind != OP_DEFORM) ++n_deform_groups;
                 }
             if (dsplit && n_deform_groups == 1) {        // (one merged launch writes these outputs; nothing else does)
@@ -946,6 +977,8 @@ struct tdrn_net {
             }
         }
         DeformArgs dargs[4];
+        const void *ts_y[4] = {nullptr, nullptr, nullptr, nullptr};
+        int ts_cs[4] = {0, 0, 0, 0};
         int n_dargs = 0;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &o = ops[oi];
@@ -1071,6 +1104,22 @@ struct tdrn_net {
                     a.out1 = io->conf + (size_t)scale_off[o.scale] * C; a.o1_bs = (long long)P * C; a.o1_ps = 3 * C;
                     a.split = 12; a.dtype = cfg.dtype;
                     dargs[n_dargs++] = a;
+                    if (o.y_t >= 0) {           // transform: Y = X * W_taps (1x1 implicit GEMM, net dtype out)
+                        ConvArgs g;
+                        g.in = a.in; g.w = wb + o.wt_off; g.bias = (const float *)(wb + o.bt_off); g.zero_page = wb;
+                        g.B = B; g.H = ti.H; g.W = ti.W; g.Cin = o.Cin; g.Ho = ti.H; g.Wo = ti.W; g.Cout = o.y_cols; g.Npad = o.y_cols;
+                        g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0; g.phases = 1; g.dtype = cfg.dtype;
+                        g.out = tptr(ws, o.y_t, B);
+                        g.o_cs = o.y_cols; g.o_rs = (long long)ti.W * o.y_cols; g.o_bs = (long long)ti.H * ti.W * o.y_cols;
+                        rc = launch_conv(g, s);
+                        if (rc != TDRN_OK) break;
+                        ts_y[n_dargs - 1] = g.out; ts_cs[n_dargs - 1] = o.y_cols;
+                    }
+                    if (!deform_batched && o.y_t >= 0) {   // ... then sample: all pyramid levels in one launch
+                        rc = launch_deform_sample_multi(dargs, ts_y, ts_cs, n_dargs, s);
+                        n_dargs = 0;
+                        break;
+                    }
                     if (!deform_batched) {      // all pyramid levels in one launch
                         const bool split = o.n_branches == 2 && deform_split;
                         if (split) {             // the two branches accumulate into zeroed outputs
