@@ -186,8 +186,19 @@ typedef struct {
     int test_phase;   /* 1: softmax on conf (phase == 'test'); 0: raw logits                */
     int dtype;        /* tdrn_dtype of the dense path                                       */
     int use_refine;   /* refinedet_vgg: ARM loc heads present (4-tuple output)               */
-    int reserved[5];
+    int plan_flags;   /* TDRN_PLAN_* bits; 0 = the default plan.  Two handles in one process may differ.   */
+    int reserved[4];
 } tdrn_net_config;
+
+/* Plan-shaping switches (tdrn_net_config.plan_flags).  Every one of them changes the launch plan only: outputs are
+ * bit-identical with the bit set or clear, except TDRN_PLAN_NO_DEFORM_TS in the 16-bit modes (where the rounding of the
+ * deformable heads sits differently; both stay inside the 16-bit drift bounds of tests/test_gpu_net.py).
+ * The environment variables of the same names (TDRN_FUSE_FIRST=0, TDRN_LATE_SIDE=0|1|2, TDRN_STREAMS=1, TDRN_DEFORM_TS=0)
+ * are diagnostics overrides read when a plan is built; a set variable wins over the flag. */
+#define TDRN_PLAN_NO_FUSE_FIRST 1   /* keep the first conv a launch of its own (its output tensor is then materialised) */
+#define TDRN_PLAN_NO_LATE_SIDE  2   /* release the side-lane convs on their true inputs instead of behind conv5_3      */
+#define TDRN_PLAN_ONE_STREAM    4   /* no side lanes: every launch on the caller's stream                              */
+#define TDRN_PLAN_NO_DEFORM_TS  8   /* deformable heads as the fused gather kernel (no transform-then-sample)           */
 
 typedef struct tdrn_net tdrn_net;
 

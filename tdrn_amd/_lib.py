@@ -24,7 +24,10 @@ class NetConfig(C.Structure):
     _fields_ = [("model", C.c_int), ("size", C.c_int), ("num_classes", C.c_int),
                 ("c7_channel", C.c_int), ("def_groups", C.c_int), ("bn", C.c_int),
                 ("multihead", C.c_int), ("deform", C.c_int), ("test_phase", C.c_int),
-                ("dtype", C.c_int), ("use_refine", C.c_int), ("reserved", C.c_int * 5)]
+                ("dtype", C.c_int), ("use_refine", C.c_int), ("plan_flags", C.c_int), ("reserved", C.c_int * 4)]
+
+
+PLAN_NO_FUSE_FIRST, PLAN_NO_LATE_SIDE, PLAN_ONE_STREAM, PLAN_NO_DEFORM_TS = 1, 2, 4, 8      # tdrn_hip.h TDRN_PLAN_*
 
 
 class NetIO(C.Structure):

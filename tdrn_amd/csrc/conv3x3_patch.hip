@@ -798,7 +798,8 @@ int patch_conv_supported(const ConvArgs &a)
     if (a.Ho != a.H || a.Wo != a.W) return 0;
     if (a.Npad % 64) return 0;
     if (a.o_rs != (long long)a.Wo * a.o_cs || a.o_bs != (long long)a.Ho * a.Wo * a.o_cs || a.o_base) return 0;
-    if ((long long)a.B * a.H * a.W * a.Cin * dtype_bytes(a.dtype) >= (1ll << 32)) return 0;
+    // (32-bit byte offsets into the input tensor; the fused-first-conv instantiation never reads it -- its input is the raw frame)
+    if (!a.fuse_x && (long long)a.B * a.H * a.W * a.Cin * dtype_bytes(a.dtype) >= (1ll << 32)) return 0;
     if (a.W % 32 == 0 && a.H % 8 == 0) return 32;
     if (a.W % 16 == 0 && a.H % 16 == 0) return 16;
     if (2 * a.W + 2 + 256 <= kPatchSlots * 8) return -1;       // flat tiles

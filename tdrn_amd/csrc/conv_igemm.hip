@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
         // PA+PB" == "K-step ks has landed".  Read a buffer only after the wait AND the barrier that
         // follow its loads; refill it only after the barrier that follows its last read.
         constexpr int LPS = PA + PB;
-        stage(0);
+        if (nk > 0) stage(0);                            // (dead-tap skipping can leave a split-K slice with no live K step)
         if (nk > 1) {
             advance();
             stage(1);
@@ -281,6 +281,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
             cur = cur + 1 == STAGES ? 0 : cur + 1;
             nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no LDS-DMA may still be in flight when the epilogue re-uses smem)
         __syncthreads();
     }
 

@@ -338,7 +338,8 @@ struct tdrn_net {
         // TDRN_DEFORM_TS=0 keeps the fused gather kernel
         {
             const char *e = getenv("TDRN_DEFORM_TS");
-            if (!(e && atoi(e) == 0) && cfg.dtype != TDRN_F32 && G == 1 && o.Cout <= 80 && (int)taps <= 34) {
+            const bool ts_on = e ? atoi(e) != 0 : !(cfg.plan_flags & TDRN_PLAN_NO_DEFORM_TS);
+            if (ts_on && cfg.dtype != TDRN_F32 && G == 1 && o.Cout <= 80 && (int)taps <= 34) {
                 o.y_cols = deform_sample_cols((int)taps);
                 o.y_t = T(o.y_cols, ti.H, ti.W);
                 o.wt_off = blob((size_t)o.y_cols * o.Cin * es);
@@ -621,8 +622,9 @@ struct tdrn_net {
         // 8x32 tiles, and nobody else reads the first conv's output (TDRN_FUSE_FIRST=0 keeps the two launches)
         {
             const char *fe = getenv("TDRN_FUSE_FIRST");
+            const bool fuse_on = fe ? atoi(fe) != 0 : !(cfg.plan_flags & TDRN_PLAN_NO_FUSE_FIRST);
             fuse_first = -1;
-            if (!(fe && atoi(fe) == 0) && cfg.dtype != TDRN_F32 && conv_patch_enabled() && ops.size() > 1 && ops[0].kind == OP_FIRST &&
+            if (fuse_on && cfg.dtype != TDRN_F32 && conv_patch_enabled() && ops.size() > 1 && ops[0].kind == OP_FIRST &&
                 ops[1].kind == OP_CONV && ops[0].stride == 1 && tensors[ops[0].out].Cpad == 64) {
                 const Op &c = ops[1];
                 const Tensor &ti = tensors[ops[0].out];
@@ -638,10 +640,11 @@ struct tdrn_net {
                 }
             }
         }
+        if (cfg.plan_flags & TDRN_PLAN_NO_LATE_SIDE) late_side = 0;
         if (const char *e = getenv("TDRN_LATE_SIDE")) late_side = atoi(e);
         if (const char *e = getenv("TDRN_SIDE_GRID")) side_grid = atoi(e);
         if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 32;
-        // split-K per layer from its geometry only (reference batch 8), so that a frame's arithmetic never
+        // split-K per layer from its geometry only (at the reference batch, 32 unless TDRN_SPLITK_REF says otherwise), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
         {
             size_t lane_bytes[kLanes] = {0, 0, 0, 0};
@@ -682,7 +685,8 @@ struct tdrn_net {
             for (const Op &o : ops)
                 if (o.kind == OP_CONV && o.stat == ST_CONV3 && o.lane == 0 && o.Cin >= 256 && o.Npad % 256 == 0) ws_fixed = align_up(conv_pp_sk_bytes(), 256);
         const char *e = getenv("TDRN_STREAMS");
-        if (e && atoi(e) <= 1) use_lanes = false;
+        if (cfg.plan_flags & TDRN_PLAN_ONE_STREAM) use_lanes = false;
+        if (e) use_lanes = atoi(e) > 1;
         const char *ds = getenv("TDRN_DEFORM_SPLIT");
         if (ds && atoi(ds) == 0) deform_split = false;
         tensor_lane.assign(tensors.size(), 0);
@@ -1044,6 +1048,15 @@ struct tdrn_net {
                     if (o.splitk > 1) {
                         a.splitk = o.splitk;
                         a.partial = (char *)ws + splitk_off[o.lane] * (size_t)B;
+                    }
+                    if (a.fuse_x && !(conv_patch_enabled() && patch_conv_supported(a) > 0)) {
+                        // the fusion was planned from the layer geometry; should the patch kernel decline THIS launch (a limit
+                        // that depends on the batch), run the two layers as two launches: the first conv's tensor keeps its place
+                        // in the workspace
+                        rc = launch_first_conv(io->x, a.fuse_w, a.fuse_b, tptr(ws, ops[0].out, B), B, ops[0].hw, ops[0].stride, ops[0].Cout,
+                                               tensors[ops[0].out].Cpad, ops[0].relu, cfg.dtype, s);
+                        if (rc != TDRN_OK) break;
+                        a.fuse_x = nullptr; a.fuse_w = nullptr; a.fuse_b = nullptr; a.fuse_cout = 0;
                     }
                     if (o.pool_t >= 0) {
                         const Tensor &tp = tensors[o.pool_t];

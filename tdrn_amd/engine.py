@@ -14,13 +14,13 @@ from ._lib import NetConfig, NetIO, KernelStat, check, ptr
 
 class NetEngine(object):
     def __init__(self, model, size, num_classes=21, c7_channel=1024, def_groups=1, bn=True,
-                 multihead=False, deform=False, test_phase=True, dtype="fp32", use_refine=False):
+                 multihead=False, deform=False, test_phase=True, dtype="fp32", use_refine=False, plan_flags=0):
         self.lib = _lib.lib()
         self.dtype_name = dtype
         cfg = NetConfig(model=model, size=size, num_classes=num_classes, c7_channel=c7_channel,
                         def_groups=def_groups, bn=int(bool(bn)), multihead=int(bool(multihead)),
                         deform=int(bool(deform)), test_phase=int(bool(test_phase)),
-                        dtype=_lib.DTYPES[dtype], use_refine=int(bool(use_refine)))
+                        dtype=_lib.DTYPES[dtype], use_refine=int(bool(use_refine)), plan_flags=int(plan_flags))
         self.cfg = cfg
         h = C.c_void_p()
         check(self.lib.tdrn_net_create(C.byref(cfg), C.byref(h)), "tdrn_net_create")

@@ -20,6 +20,16 @@ class EngineModule(nn.Module):
         object.__setattr__(self, "compute_dtype", os.environ.get("TDRN_DTYPE", "fp32"))
 
     # precision switches select the MFMA input type instead of casting the fp32 master params
+    def set_plan_flags(self, flags):
+        """tdrn_hip.h TDRN_PLAN_* bits of the next engine this module builds (0 = the default plan)."""
+        args = dict(self._engine_args)
+        args["plan_flags"] = int(flags)
+        object.__setattr__(self, "_engine_args", args)
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_size_engines", {})
+        object.__setattr__(self, "_dirty", True)
+        return self
+
     def set_compute_dtype(self, name):
         object.__setattr__(self, "compute_dtype", name)
         object.__setattr__(self, "_engine", None)

@@ -34,6 +34,14 @@ def _worker(rank, world, port, n_frames, q):
     sl = tdist.shard_slice(n_frames, rank, world)
     local = frames[sl] + 1.0                      # stand-in for per-frame independent inference
     got = tdist.gather_results((sl.start, local), rank, world, dst=0)
+    # the data-plane form: one tensor gather of the (b_local, C, top_k, 5)-shaped detections, ragged over the ranks
+    det = torch.from_numpy(local).reshape(-1, 1, 1, 1).repeat(1, 2, 3, 5)
+    gt = tdist.gather_results(det, rank, world, dst=0)
+    if rank == 0:
+        assert [int(g.shape[0]) for g in gt] == [len(range(n_frames)[tdist.shard_slice(n_frames, k, world)]) for k in range(world)]
+        assert torch.equal(torch.cat(gt, 0)[:, 0, 0, 0], torch.from_numpy(frames + 1.0))
+    else:
+        assert gt is None
     t = tdist.max_over_ranks(1.0 + rank)
     assert t == float(world)
     tdist.barrier()

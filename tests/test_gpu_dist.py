@@ -66,3 +66,24 @@ def test_bench_py_two_ranks_one_gpu():
     assert d["config"]["global_batch"] == 8 and d["value"] > 0
     assert abs(d["value"] - 2 * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3            # whole-job frames / max-over-ranks time
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+def test_bench_py_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun variables in the environment -- the driver's command form -- starts two
+    fresh ranks itself (before the parent touches a GPU), relays rank 0's line and its exit code.  On this 1-GPU box the ranks
+    share device 0 over gloo (TDRN_DIST_ONE_DEVICE / TDRN_DIST_BACKEND: test-only switches; on a node every rank has its own
+    GPU and the backend is RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TDRN_DIST_BACKEND="gloo", TDRN_DIST_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "3", "--warmup", "2",
+                        "--reps", "2", "--no-cpu-baseline", "--no-parity"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["steps"] == 3 and d["value"] > 0
+    # a rank that fails makes the launcher fail
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "1", "--size", "333"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode != 0

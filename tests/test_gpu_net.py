@@ -574,22 +574,20 @@ def test_hipgraph_replay_equals_eager():
 @pytest.mark.parametrize("model,args", [("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True)), ("ssd4scale_vgg", (320, 21, 1024, False, False))])
 def test_fused_first_conv_equals_two_launches(model, args, monkeypatch):
     """16-bit plans compute the first conv inside conv1_2's patch loader (conv3x3_patch.hip FUSE): same operand layout and
-    instruction as the stand-alone kernel, so every output is BIT-identical to the two-launch plan (TDRN_FUSE_FIRST=0) --
+    instruction as the stand-alone kernel, so every output is BIT-identical to the two-launch plan (plan_flags TDRN_PLAN_NO_FUSE_FIRST) --
     at the build size, at other frame sizes (tiles at every border, fewer items than CUs) and at batch 1 / 3 / 8."""
     # (the multihead DRN needs a >= 5x5 coarsest map for its 5x5 deformable heads: sizes from 320 up)
     cases = [(320, 3), (320, 8), (384, 3), (448, 1), (704, 1)] + ([(192, 3), (256, 1)] if model == "ssd4scale_vgg" else [])
+    monkeypatch.delenv("TDRN_FUSE_FIRST", raising=False)
     for dtype in ("bf16", "fp16"):
-        monkeypatch.setenv("TDRN_FUSE_FIRST", "1")
-        fused, _ = _build(model, args)
+        fused, _ = _build(model, args)                       # two handles in one process, differing only in plan_flags
         fused.set_compute_dtype(dtype)
-        monkeypatch.setenv("TDRN_FUSE_FIRST", "0")
         plain, _ = _build(model, args)
+        plain.set_plan_flags(_lib.PLAN_NO_FUSE_FIRST)
         plain.set_compute_dtype(dtype)
         for size, batch in cases:
             x = torch.from_numpy(synth.synth_frames(batch, size, seed=70 + size + batch)).to(DEV)
-            monkeypatch.setenv("TDRN_FUSE_FIRST", "1")
             a = fused(x)
-            monkeypatch.setenv("TDRN_FUSE_FIRST", "0")
             b = plain(x)
             for u, v in zip(a, b):
                 if torch.is_tensor(u):
@@ -608,3 +606,30 @@ def test_fused_first_conv_equals_two_launches(model, args, monkeypatch):
             names.append([o["name"].split(":")[0] for o in eng.op_stats()])
             eng.set_profile(0)
         assert "first_conv" not in names[0] and names[1][0] == "first_conv"
+
+
+def test_frame_stream_equals_unstreamed():
+    """tdrn_amd.stream.FrameStream (pinned uint8 frames -> H2D -> preprocess -> net -> Detect -> D2H, two slots in flight on
+    three streams; test_video.py:98-115 as a pipeline) returns, batch after batch, exactly what the same step gives without
+    capture, slots or copies -- also when a slot is re-used while its neighbours are still in flight."""
+    from tdrn_amd.stream import FrameStream
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    net.set_compute_dtype("fp16")
+    eng = net.engine(DEV)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    B = 3
+    fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B)
+    rng = np.random.RandomState(11)
+    feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)).pin_memory() for _ in range(5)]
+    slots = [fs.submit(f) for f in feeds[:2]]
+    results = []
+    for k in range(2, 7):                                  # keep two batches in flight; read a slot just before re-using it
+        s = slots[k - 2]
+        results.append(fs.result(s).clone())
+        slots.append(fs.submit(feeds[k % 5]))
+    fs.drain()
+    order = [0, 1, 2, 3, 4]
+    for k, got in zip(order, results):
+        want = fs.eager(feeds[k].to(DEV)).cpu()
+        assert torch.equal(got, want), k
+    assert (results[0][..., 0] > 0).any()                  # (not vacuous: there are detections)
