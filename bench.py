@@ -407,6 +407,7 @@ def main():
     if world == 1 and NS == 1 and not args.no_modes:
         modes = {}
         for dtm in [d for d in ("fp16", "fp32", "bf16") if d != args.dtype]:
+            print("bench.py: timing the %s mode" % dtm, file=sys.stderr, flush=True)
             net.set_compute_dtype(dtm)
             e2 = net.engine(dev)
             st2 = make_stepper(e2, Detect(21, 0, 200, 0.01, 0.45))

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "kernels.h"
@@ -60,6 +61,34 @@ struct Op {
     int pool_t = -1;                                       // conv: fused MaxPool2d(2,2) output tensor (patch kernel)
     int splitk = 1;                                        // conv: K slices, fixed per layer at plan time
 };
+
+// Side-lane streams and no-timing events are POOLED per process instead of destroyed with their net: a hipGraph captured for
+// a net created after another net's streams / events had been destroyed crashed inside hipGraphLaunch (ROCm 7.2; reproduced
+// with bench.py's three engines: a 16-bit engine destroyed, then the fp32 engine's step captured and replayed).  A net takes
+// them from the pool and hands them back in tdrn_net_destroy; nothing in the pool is ever in use by two nets at a time.
+namespace pool {
+std::mutex mu;
+std::vector<hipStream_t> streams;
+std::vector<hipEvent_t> events;
+int get_stream(hipStream_t *s)
+{
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!streams.empty()) { *s = streams.back(); streams.pop_back(); return TDRN_OK; }
+    }
+    return hip_status(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+}
+int get_event(hipEvent_t *e)
+{
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!events.empty()) { *e = events.back(); events.pop_back(); return TDRN_OK; }
+    }
+    return hip_status(hipEventCreateWithFlags(e, hipEventDisableTiming));
+}
+void put_stream(hipStream_t s) { if (s) { std::lock_guard<std::mutex> g(mu); streams.push_back(s); } }
+void put_event(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); events.push_back(e); } }
+}  // namespace pool
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
                             "deform_gemm_mfma", "softmax21", "layout", "conv3x3_patch_mfma"};
@@ -705,14 +734,14 @@ struct tdrn_net {
     {
         if (lanes_ready) return TDRN_OK;
         for (int i = 0; i < kLanes - 1; ++i) {
-            TDRN_HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
-            TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+            TDRN_TRY(pool::get_stream(&side[i]));
+            TDRN_TRY(pool::get_event(&ev_join[i]));
         }
-        TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        TDRN_HIP_TRY(hipEventCreateWithFlags(&ev_zero, hipEventDisableTiming));
+        TDRN_TRY(pool::get_event(&ev_fork));
+        TDRN_TRY(pool::get_event(&ev_zero));
         tensor_ev.assign(tensors.size(), nullptr);
         for (size_t t = 0; t < tensors.size(); ++t)
-            if (tensor_shared[t]) TDRN_HIP_TRY(hipEventCreateWithFlags(&tensor_ev[t], hipEventDisableTiming));
+            if (tensor_shared[t]) TDRN_TRY(pool::get_event(&tensor_ev[t]));
         lanes_ready = true;
         return TDRN_OK;
     }
@@ -1222,14 +1251,14 @@ int tdrn_net_create(const tdrn_net_config *cfg, tdrn_net **out)
 void tdrn_net_destroy(tdrn_net *net)
 {
     if (!net) return;
-    for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : net->tensor_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);          // (timing events of the profiling passes: never captured)
+    for (hipEvent_t e : net->tensor_ev) pool::put_event(e);
     for (int i = 0; i < tdrn_net::kLanes - 1; ++i) {
-        if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
-        if (net->side[i]) (void)hipStreamDestroy(net->side[i]);
+        pool::put_event(net->ev_join[i]);
+        pool::put_stream(net->side[i]);
     }
-    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-    if (net->ev_zero) (void)hipEventDestroy(net->ev_zero);
+    pool::put_event(net->ev_fork);
+    pool::put_event(net->ev_zero);
     delete net;
 }
 
