@@ -431,30 +431,32 @@ def main():
     if world == 1 and NS == 1 and args.stream and not args.no_detect:
         import numpy as np
         from tdrn_amd.stream import FrameStream
-        fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B)
+        fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NB)      # one pinned batch per slot: NB distinct batches cycle
         rng = np.random.RandomState(7)
-        feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)).pin_memory() for _ in range(NB)]
-        for k in range(4):
-            fs.submit(feeds[k % NB])
+        for sl in range(NB):
+            fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
+        fs.prime()
+        for k in range(2 * NB):
+            fs.run()
         fs.drain()
         t_stream = []
         for _ in range(max(3, args.reps // 2)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(args.steps):
-                fs.submit(feeds[k % NB])
+                fs.run()
             fs.drain()
             t_stream.append(time.perf_counter() - t0)
         t_stream.sort()
         ts = t_stream[len(t_stream) // 2]
-        slot = fs.submit(feeds[1 % NB])
-        got = fs.result(slot).clone()
-        want = fs.eager(feeds[1 % NB].to(dev)).cpu()
+        fs.prime()
+        got = fs.result(fs.run()).clone()
+        want = fs.eager(fs.pinned_in(0).to(dev)).cpu()
         stream_blk = {"frames_per_s": round(B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
                       "vs_resident": round((B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
-                      "per_step": "H2D %.1f MB of uint8 BGR 500x375 frames from pinned memory, tdrn_preprocess, net, Detect, D2H %.1f MB of detections; 2 slots in flight, 3 HIP streams"
-                                  % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6),
+                      "per_step": "one hipGraph per slot: H2D %.1f MB of the NEXT batch's uint8 BGR 500x375 frames (pinned) || tdrn_preprocess, net, Detect, D2H %.1f MB of detections; %d slots"
+                                  % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NB),
                       "note": "the resident figure (`value`) starts from fp32 frames already preprocessed in HBM; this one includes the preprocess kernel and both copies"}
         del fs
 

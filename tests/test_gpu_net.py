@@ -609,27 +609,30 @@ def test_fused_first_conv_equals_two_launches(model, args, monkeypatch):
 
 
 def test_frame_stream_equals_unstreamed():
-    """tdrn_amd.stream.FrameStream (pinned uint8 frames -> H2D -> preprocess -> net -> Detect -> D2H, two slots in flight on
-    three streams; test_video.py:98-115 as a pipeline) returns, batch after batch, exactly what the same step gives without
-    capture, slots or copies -- also when a slot is re-used while its neighbours are still in flight."""
+    """tdrn_amd.stream.FrameStream (per slot one hipGraph: copy-in of the next slot's pinned uint8 frames || preprocess -> net
+    -> Detect -> copy-out; test_video.py:98-115 as a pipeline) returns, batch after batch, exactly what the same step gives
+    without capture, slots or copies -- also when a slot's buffers are re-used turn after turn."""
     from tdrn_amd.stream import FrameStream
     net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
     net.set_compute_dtype("fp16")
     eng = net.engine(DEV)
     pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
-    B = 3
-    fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B)
+    B, slots = 3, 2
+    fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots)
     rng = np.random.RandomState(11)
-    feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)).pin_memory() for _ in range(5)]
-    slots = [fs.submit(f) for f in feeds[:2]]
+    feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)) for _ in range(5)]
+    fs.prime(feeds[0])
     results = []
-    for k in range(2, 7):                                  # keep two batches in flight; read a slot just before re-using it
-        s = slots[k - 2]
+    for k in range(5):                                     # batch k runs in slot k % 2; batch k+1 is handed over before the launch
+        if k + 1 < 5:
+            if k + 1 >= slots:
+                fs.result((k + 1) % slots)                 # (the turn that last used that slot's buffers has finished)
+            fs.pinned_in((k + 1) % slots).copy_(feeds[k + 1])
+        s = fs.run()
+        assert s == k % slots
         results.append(fs.result(s).clone())
-        slots.append(fs.submit(feeds[k % 5]))
     fs.drain()
-    order = [0, 1, 2, 3, 4]
-    for k, got in zip(order, results):
+    for k, got in enumerate(results):
         want = fs.eager(feeds[k].to(DEV)).cpu()
         assert torch.equal(got, want), k
     assert (results[0][..., 0] > 0).any()                  # (not vacuous: there are detections)
