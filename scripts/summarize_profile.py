@@ -71,11 +71,30 @@ def main():
             seen = collections.Counter()
             for r in f:
                 n = short(r["Kernel_Name"])
-                fam = "patch" if n.startswith("conv3x3_patch") else ("igemm" if n.startswith("conv_igemm") else n.split("<")[0])
+                # (one family: the loader/consumer kernel and the all-waves-compute kernel share the 3x3 layers of a plan)
+                fam = "patch" if (n.startswith("conv3x3_patch") or n.startswith("conv3x3_pp")) else ("igemm" if n.startswith("conv_igemm") else n.split("<")[0])
                 acc[(fam, seen[fam])].append(value(r))
                 seen[fam] += 1
         return {k: sum(v) / len(v) for k, v in acc.items()}
     dur = per_family(tr, lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    # the same from the trace of the hipGraph REPLAY (what bench.py times): dispatch ids follow the graph's node order, so the
+    # launches are grouped per replay by timestamp order instead
+    trg_rows = trace_rows(os.path.join(src, "trace_graph"), "kernel_trace")
+    graph_line = None
+    if trg_rows:
+        trg_rows = [r for r in trg_rows if "tdrn" in r["Kernel_Name"]]
+        fam_rows = [r for r in trg_rows if short(r["Kernel_Name"]).startswith(("conv3x3_patch", "conv3x3_pp"))]
+        # the last 3/4 of the dispatches: the timed loop (warm-up and capture passes come first)
+        fam_rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        fam_rows = fam_rows[len(fam_rows) // 4:]
+        us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fam_rows]
+        if us:
+            graph_line = (sum(us) / len(us), len(us))
+        ksg = glob.glob(os.path.join(src, "trace_graph", "**", "*_kernel_stats.csv"), recursive=True)
+        if ksg:
+            shutil.copy(ksg[0], os.path.join(dst, "kernel_stats_graph_replay.csv"))
+        if os.path.exists(os.path.join(src, "bench_traced_graph.json")):
+            shutil.copy(os.path.join(src, "bench_traced_graph.json"), os.path.join(dst, "bench_traced_graph.json"))
     # ---- counters --------------------------------------------------------------------------------------------
     def counters(sub):
         rows = trace_rows(os.path.join(src, sub), "counter_collection")
@@ -95,7 +114,7 @@ def main():
     sq_dur = per_family(sq, lambda r: r.get("dur", 0.0))
     # ---- per-layer table ---------------------------------------------------------------------------------------
     fam_of = lambda name: {"conv3x3_patch_mfma": "patch", "conv_igemm_mfma": "igemm", "first_conv": "first_conv_mfma_kernel",
-                           "deform_gemm_mfma": "deform_gemm_kernel"}.get(name.split(":")[0])
+                           "deform_gemm_mfma": "deform_sample_kernel"}.get(name.split(":")[0])
     seen = collections.Counter()
     rows = [["launch", "alone_us", "in_step_us", "trace_us", "gflop", "tflops_alone", "frac_of_2500_alone", "tflops_in_loop", "frac_in_loop",
              "mfma_busy_share", "hbm_MB", "algorithmic_MB", "eff_clock_ghz"]]
@@ -107,7 +126,7 @@ def main():
             continue
         k = (fam, seen[fam])
         # an igemm op with split-K is two or three dispatches (GEMM + reduce): only single-dispatch families get counters
-        single = fam in ("patch", "first_conv_mfma_kernel", "deform_gemm_kernel")
+        single = fam in ("patch", "first_conv_mfma_kernel", "deform_sample_kernel")
         seen[fam] += 1
         t = dur.get(k) if single else None
         tf_a = o["gflop"] / o["alone_us"] * 1e3 if o["alone_us"] else 0.0   # GFLOP / us = PFLOP/s
@@ -160,11 +179,23 @@ def main():
             d = json.load(open(tj))
         except (OSError, ValueError):
             d = {}
-        d["conv3x3_patch_mfma|320|bf16|32"] = {"hbm_bytes_per_launch": int(patch_hbm * 1e6 / n_patch), "launches": n_patch,
+        build = None
+        try:
+            build = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]).get("build")
+        except (OSError, ValueError, IndexError):
+            pass
+        d["conv3x3_patch_mfma|320|bf16|32"] = {"hbm_bytes_per_launch": int(patch_hbm * 1e6 / n_patch), "launches": n_patch, "build": build,
                                                "source": os.path.basename(os.path.abspath(dst)) + "/per_layer.csv (2 x FETCH_SIZE + WRITE_SIZE)"}
         json.dump(d, open(tj, "w"), indent=1)
         print("conv3x3_patch family in the timed loop (kernel trace): %.1f us over %d launches = %.1f TFLOP/s = %.3f of peak; HBM %.1f MB per launch"
               % (patch_trace_us, n_patch, patch_gflop / patch_trace_us * 1e3, patch_gflop / patch_trace_us * 1e3 / PEAK, patch_hbm / n_patch))
+        if graph_line:
+            gus, gn = graph_line
+            print("conv3x3 family in the hipGraph REPLAY (kernel trace of what bench.py times): %.1f us per launch over %d launches = %.1f TFLOP/s = %.3f of peak"
+                  % (gus, gn, patch_gflop / n_patch / gus * 1e3, patch_gflop / n_patch / gus * 1e3 / PEAK))
+            with open(os.path.join(dst, "graph_replay_family.txt"), "w") as f:
+                f.write("conv3x3 family (conv3x3_patch_kernel + conv3x3_pp_kernel), rocprofv3 --kernel-trace of `bench.py --graph 1`: %.2f us per launch over %d launches "
+                        "= %.1f TFLOP/s = %.4f of 2500\n" % (gus, gn, patch_gflop / n_patch / gus * 1e3, patch_gflop / n_patch / gus * 1e3 / PEAK))
 
 
 if __name__ == "__main__":
