@@ -513,6 +513,115 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The transform: Y[pixel][col] = sum_c X[pixel][c] * Wt[col][c] with K = Cin = 256 and N = taps x 80 columns (2816).
+// A short-K GEMM: conv_igemm.hip runs it at 0.4 PFLOP/s (four K steps per tile: prologue, epilogue and the 288-MB result
+// dominate; one 256x128 tile per workgroup, nothing overlaps).  Here the WEIGHTS LIVE IN REGISTERS: a wave owns 32 columns,
+// i.e. 32 x 256 weights = 16 MFMA A-fragments = 64 registers, loaded once; the workgroup (8 waves = 256 columns) then
+// streams 32-pixel activation tiles (16 KiB, LDS-DMA, double-buffered) past them: per tile and wave 16 ds_read_b128 +
+// 16 MFMAs and 4 eight-byte stores per lane.  LDS-DMA volume 16 B/clk per CU, no weight traffic at all after the prologue;
+// two workgroups per CU cover each other's barriers.  grid = (N / 256 column groups) x (pixel partitions).
+// ---------------------------------------------------------------------------------------------
+struct YGemmParams {
+    const char *x;     // [M][256] DT
+    const char *w;     // [N][256] DT
+    char *y;           // [M][ycs] DT
+    int M, N, ycs, parts, tiles_per_part;
+};
+
+template <typename DT>
+__global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
+{
+    constexpr int TP = 32;                               // pixels per tile
+    constexpr int TBYTES = TP * 512;                     // 16 KiB
+    __shared__ __attribute__((aligned(16))) char smem[2 * TBYTES];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int cg = blockIdx.x, part = blockIdx.y;
+    const int col0 = cg * 256 + wave * 32;
+    // my 32 columns x 256 channels: fragment kk = channels [16kk + 8hh, +8) of column col0 + r32
+    u32x4 wf[16];
+    {
+        const char *wr = p.w + ((size_t)(col0 + r32) * 256 + 8 * hh) * 2;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wf[kk] = *(const u32x4 *)(wr + kk * 32);
+    }
+    const int t0 = part * p.tiles_per_part;
+    int nt = (p.M + TP - 1) / TP - t0;
+    nt = nt < p.tiles_per_part ? nt : p.tiles_per_part;
+    if (nt <= 0) return;
+    // staging: a tile = 32 rows x 512 B = 16 pieces of 1 KiB (2 rows each); wave w issues pieces 2w, 2w+1.
+    // LDS image linear; the 16-byte chunk c of row r is stored at chunk position c ^ (r & 31) (swizzle on the SOURCE address)
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = 2 * wave + j;
+            const int row = 2 * piece + (lane >> 5), cpos = lane & 31;
+            long long m = (long long)(t0 + t) * TP + row;
+            if (m >= p.M) m = p.M - 1;                   // (rows past the end re-read the last pixel; their results are not stored)
+            const char *src = p.x + (size_t)m * 512 + ((cpos ^ (row & 31)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + buf * TBYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) {
+            stage(t + 1, buf ^ 1);                       // (its last readers passed the barrier that ended tile t-1)
+            // tile t's two pieces must have landed; younger than them and free to stay in flight: the previous tile's FOUR
+            // 8-byte stores (always issued: a tile inside the partition has a live lane) and the two pieces just issued
+            if (t == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                    // (raw: __syncthreads() would drain the piece just issued)
+        asm volatile("" ::: "memory");
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const char *ab = smem + buf * TBYTES + r32 * 512;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const u32x4 a = *(const u32x4 *)(ab + (((2 * kk + hh) ^ r32) << 4));
+            MmaD<DT>::run(wf[kk], a, acc);
+        }
+        // lane = pixel r32; register e = column (e & 3) + 8 (e >> 2) + 4 hh of my 32: four 8-byte stores
+        const long long m = (long long)(t0 + t) * TP + r32;
+        if (m < p.M) {
+            char *yr = p.y + ((size_t)m * p.ycs + col0) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(uint2 *)(yr + (8 * g + 4 * hh) * 2) = make_uint2(pack2<DT>(acc[4 * g], acc[4 * g + 1]), pack2<DT>(acc[4 * g + 2], acc[4 * g + 3]));
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // my LDS reads of tile t have returned ...
+        __builtin_amdgcn_s_barrier();                    // ... and everybody's: its buffer may be refilled
+        asm volatile("" ::: "memory");
+    }
+}
+
+int ygemm_supported(int Cin, int ycols, int dtype) { return dtype != TDRN_F32 && Cin == 256 && ycols % 256 == 0; }
+
+int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s)
+{
+    if (!ygemm_supported(256, N, dtype) || M <= 0 || M >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
+    YGemmParams p;
+    p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
+    p.M = (int)M; p.N = N; p.ycs = ycs;
+    const int tiles = (int)((M + 31) / 32), cgs = N / 256;
+    // ~4 workgroups per CU in flight over the whole launch; a partition is at least 8 tiles (the weight prologue is 8 KiB per wave)
+    int parts = (1024 + cgs - 1) / cgs;
+    if (parts > (tiles + 7) / 8) parts = (tiles + 7) / 8;
+    if (parts < 1) parts = 1;
+    p.parts = parts;
+    p.tiles_per_part = (tiles + parts - 1) / parts;
+    dim3 grid((unsigned)cgs, (unsigned)parts);
+    if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t>), grid, dim3(512), 0, s, p);
+    return hip_status(hipGetLastError());
+}
+
 // the fast path takes: 16-bit, stride 1, one deformable group, at most two branches with at most 34 taps together, Cout <= 80
 int deform_sample_supported(const DeformArgs &a)
 {
@@ -525,7 +634,7 @@ int deform_sample_supported(const DeformArgs &a)
     }
     return taps <= 34 ? taps : 0;
 }
-int deform_sample_cols(int taps) { return (int)align_up((size_t)taps * kSampleCols, 128); }
+int deform_sample_cols(int taps) { return (int)align_up((size_t)taps * kSampleCols, 256); }
 
 // y[i]: the level's Y tensor ([B*H*W][ycs[i]], net dtype), computed by the caller's 1x1 GEMM with the branches' taps in order
 int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s)

@@ -137,6 +137,9 @@ int deform_n_pad(int cout);
 int deform_sample_supported(const DeformArgs &a);      // 0 = no, else the number of taps of all branches
 int deform_sample_cols(int taps);
 int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s);
+// Y = X[M][256] * Wt[N][256]^T in the net dtype, weights held in registers (deform.hip); N % 256 == 0
+int ygemm_supported(int Cin, int ycols, int dtype);
+int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Detect (detect.hip)

@@ -1153,7 +1153,10 @@ struct tdrn_net {
                         g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0; g.phases = 1; g.dtype = cfg.dtype;
                         g.out = tptr(ws, o.y_t, B);
                         g.o_cs = o.y_cols; g.o_rs = (long long)ti.W * o.y_cols; g.o_bs = (long long)ti.H * ti.W * o.y_cols;
-                        rc = launch_conv(g, s);
+                        if (ygemm_supported(o.Cin, o.y_cols, cfg.dtype))
+                            rc = launch_ygemm(g.in, g.w, g.out, (long long)B * ti.H * ti.W, o.y_cols, o.y_cols, cfg.dtype, s);
+                        else
+                            rc = launch_conv(g, s);
                         if (rc != TDRN_OK) break;
                         ts_y[n_dargs - 1] = g.out; ts_cs[n_dargs - 1] = o.y_cols;
                     }
