@@ -534,7 +534,9 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
 {
     constexpr int TP = 32;                               // pixels per tile
     constexpr int TBYTES = TP * 512;                     // 16 KiB
+    constexpr int SROW = 512 + 16;                       // staging row: 256 columns + a 16-byte pad (bank spread)
     __shared__ __attribute__((aligned(16))) char smem[2 * TBYTES];
+    __shared__ __attribute__((aligned(16))) char sst[TP * SROW];     // the output tile [pixel][256 columns]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
     const int cg = blockIdx.x, part = blockIdx.y;
@@ -569,10 +571,10 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
         const int buf = t & 1;
         if (t + 1 < nt) {
             stage(t + 1, buf ^ 1);                       // (its last readers passed the barrier that ended tile t-1)
-            // tile t's two pieces must have landed; younger than them and free to stay in flight: the previous tile's FOUR
-            // 8-byte stores (always issued: a tile inside the partition has a live lane) and the two pieces just issued
+            // tile t's two pieces must have landed; younger than them and free to stay in flight: the previous tile's TWO
+            // 16-byte stores (always issued: a tile inside the partition has a live row) and the two pieces just issued
             if (t == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -587,17 +589,29 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
             const u32x4 a = *(const u32x4 *)(ab + (((2 * kk + hh) ^ r32) << 4));
             MmaD<DT>::run(wf[kk], a, acc);
         }
-        // lane = pixel r32; register e = column (e & 3) + 8 (e >> 2) + 4 hh of my 32: four 8-byte stores
-        const long long m = (long long)(t0 + t) * TP + r32;
-        if (m < p.M) {
-            char *yr = p.y + ((size_t)m * p.ycs + col0) * 2;
+        // lane = pixel r32; register e = column (e & 3) + 8 (e >> 2) + 4 hh of my 32.  The tile goes through an LDS image
+        // [pixel][256 columns] so that the stores are whole 128-byte lines (512 B per pixel row, 16 B per lane): written as
+        // 8-byte pieces straight from the registers, a line of Y was assembled from eight partial writes (222 -> 167 us for
+        // the four levels).  The staging stores are inline asm: in front of an LDS store it can see, hipcc drains every LDS-DMA
+        // piece in flight with a vmcnt(0).
+        const unsigned sa = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)sst + (unsigned)(r32 * SROW + (wave * 32 + 4 * hh) * 2);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(uint2 *)(yr + (8 * g + 4 * hh) * 2) = make_uint2(pack2<DT>(acc[4 * g], acc[4 * g + 1]), pack2<DT>(acc[4 * g + 2], acc[4 * g + 3]));
+        for (int g = 0; g < 4; ++g) {
+            const uint2 v = make_uint2(pack2<DT>(acc[4 * g], acc[4 * g + 1]), pack2<DT>(acc[4 * g + 2], acc[4 * g + 3]));
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(v), "n"(16 * g) : "memory");
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);              // my LDS reads of tile t have returned ...
-        __builtin_amdgcn_s_barrier();                    // ... and everybody's: its buffer may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // my LDS reads of tile t have returned, my staging writes are done ...
+        __builtin_amdgcn_s_barrier();                    // ... and everybody's: tile t's buffer may be refilled, the image is whole
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = (threadIdx.x >> 5) + 16 * q, ch = threadIdx.x & 31;      // 32 lanes = one pixel row of 512 B
+            const long long m = (long long)(t0 + t) * TP + row;
+            if (m < p.M) *(u32x4 *)(p.y + ((size_t)m * p.ycs + cg * 256) * 2 + ch * 16) = *(const u32x4 *)(sst + row * SROW + ch * 16);
+        }
+        // (the next tile's staging writes come behind the barrier at the top of the next iteration: no wave can still be
+        // reading this image then)
     }
 }
 
