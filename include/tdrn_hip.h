@@ -102,6 +102,16 @@ TDRN_API int tdrn_nms_topk(const float *dets, int n, float overlap, float min_sc
                            int32_t *keep_out, int32_t *num_out, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* The per-class loop of DetectOTA.forward (layers/functions/detection_ota.py:61-79: for cl in 1..C-1: c_mask, nms(boxes,
+ * scores, nms_thresh, top_k)) as ONE launch: boxes (n,4) shared by all classes, scores (n, num_classes) row-major (the softmax
+ * output of one frame); class c in [first_class, num_classes) runs tdrn_nms_topk's rule on (boxes, scores[:, c]).
+ * keep_out (num_classes, n) int32 and num_out (num_classes): rows below first_class are not written.  n <= 16384
+ * (TDRN_E_UNSUPPORTED beyond: call tdrn_nms_topk per class).  No host round trip: the caller reads num_out once. */
+TDRN_API size_t tdrn_nms_topk_classes_workspace_bytes(int n, int num_classes);
+TDRN_API int tdrn_nms_topk_classes(const float *boxes, const float *scores, int n, int num_classes, int first_class,
+                                   float overlap, float min_score, int top_k, int32_t *keep_out, int32_t *num_out,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* COMPAT twin of   void _nms(int* keep_out, int* num_out, const float* boxes_host,
  *     int boxes_num, int boxes_dim, float nms_overlap_thresh, int device_id)
  *                                                          utils/nms/gpu_nms.hpp:1-2

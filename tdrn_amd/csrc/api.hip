@@ -124,6 +124,16 @@ int tdrn_nms_topk(const float *dets, int n, float overlap, float min_score, int 
                       top_k);
 }
 
+size_t tdrn_nms_topk_classes_workspace_bytes(int n, int num_classes) { return nms_classes_workspace_bytes(n, num_classes); }
+
+int tdrn_nms_topk_classes(const float *boxes, const float *scores, int n, int num_classes, int first_class, float overlap, float min_score,
+                          int top_k, int32_t *keep_out, int32_t *num_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (top_k < 0) return TDRN_E_ARG;
+    return launch_nms_classes(boxes, scores, n, num_classes, first_class, overlap, min_score, top_k, keep_out, num_out, workspace,
+                              workspace_bytes, (hipStream_t)stream);
+}
+
 int tdrn_gpu_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
                       float nms_overlap_thresh, int device_id)
 {

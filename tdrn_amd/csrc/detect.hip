@@ -688,28 +688,40 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
 
 // ---- stand-alone NMS (cpu_nms / gpu_nms twins): one workgroup, keep list in global memory ------
 // sort key of box i: (score key | presorted: descending rank) : ~index
-__device__ __forceinline__ unsigned long long nms_key(const float *__restrict__ dets, int n, int presorted, int i, float min_score = -INFINITY)
+// where a launch finds its boxes and scores: (n,5) rows [x1,y1,x2,y2,score] (box = dets, stride 5; score = dets + 4, stride 5), or
+// a shared (n,4) box table with one score COLUMN per workgroup (DetectOTA: box stride 4; score = conf + class, stride C)
+struct NmsSrc {
+    const float *box; int bstride;
+    const float *score; int sstride;
+    int score_wg_step;             // floats added to `score` per blockIdx.x (0: one problem)
+    long long kept_wg_bytes;       // bytes added to the keep-list scratch / keep_out (x n ints) / num_out (x 1) per blockIdx.x
+};
+__device__ __forceinline__ unsigned long long nms_key(const float *__restrict__ score, int sstride, int n, int presorted, int i, float min_score = -INFINITY)
 {
     if (i >= n) return 0ull;
-    if (!presorted && !(dets[(size_t)i * 5 + 4] > min_score)) return 0ull;       // not a candidate: sorts behind every candidate
-    // presorted: keep the caller's order (gpu_nms.pyx:25-28 sorts on the host)
-    const unsigned hi = presorted ? (unsigned)(n - i) : score_key(dets[(size_t)i * 5 + 4]);
+    if (!presorted && !(score[(size_t)i * sstride] > min_score)) return 0ull;       // not a candidate: sorts behind every candidate
+    const unsigned hi = presorted ? (unsigned)(n - i) : score_key(score[(size_t)i * sstride]);
     return ((unsigned long long)hi << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
 }
 
 // GK = false: the n <= 16384 keys are built and sorted in LDS.  GK = true: `gkeys` holds them, sorted, in global memory.
 template <bool GK>
-__global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict__ dets, int n, NmsRule rule, int presorted,
+__global__ __launch_bounds__(256) void nms_plain_kernel(NmsSrc src, int n, NmsRule rule, int presorted,
                                                         const unsigned long long *__restrict__ gkeys,
                                                         void *__restrict__ kept_mem, int *__restrict__ keep_out,
                                                         int *__restrict__ num_out, float min_score, int pre_top_k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dsm[];     // (no static LDS beside it: cdna guide G17)
+    // one workgroup = one problem; blockIdx.x > 0: the next score column over the same boxes (all classes of a frame in ONE launch)
+    const float *score = src.score + (size_t)blockIdx.x * src.score_wg_step;
+    kept_mem = (char *)kept_mem + (size_t)blockIdx.x * src.kept_wg_bytes;
+    keep_out += (size_t)blockIdx.x * n;
+    num_out += blockIdx.x;
     const unsigned long long *sk = GK ? gkeys : dsm;
     if constexpr (!GK) {
         int N = 64;
         while (N < n) N <<= 1;
-        for (int i = threadIdx.x; i < N; i += 256) dsm[i] = nms_key(dets, n, presorted, i, min_score);
+        for (int i = threadIdx.x; i < N; i += 256) dsm[i] = nms_key(score, src.sstride, n, presorted, i, min_score);
         __syncthreads();
         if (!presorted) bitonic_sort_desc(dsm, N, threadIdx.x, 256);
     }
@@ -718,13 +730,13 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict_
     int n_cand = 0;     // candidates = the non-zero keys (they sort first); at most pre_top_k of them enter the NMS (box_utils.py:251)
     for (int i = threadIdx.x; i < n; i += 64) n_cand += sk[i] != 0ull ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
-    n = pre_top_k > 0 && n_cand > pre_top_k ? pre_top_k : n_cand;
-    const KeepList kept(kept_mem, n > 0 ? n : 1);
+    const int nn = pre_top_k > 0 && n_cand > pre_top_k ? pre_top_k : n_cand;
+    const KeepList kept(kept_mem, nn > 0 ? nn : 1);
     const int nk = wave_greedy_nms(
-        n, n, rule, kept,
+        nn, nn, rule, kept,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
-            const float *d = dets + (size_t)p * 5;
+            const float *d = src.box + (size_t)p * src.bstride;
             bx.x1 = d[0]; bx.y1 = d[1]; bx.x2 = d[2]; bx.y2 = d[3];
             bx.area = box_area(d[0], d[1], d[2], d[3], rule.plain);
         },
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(256) void nms_tile_sort_kernel(const float *__restr
 {
     __shared__ unsigned long long t[kSortTile];
     const int base = blockIdx.x * kSortTile;
-    for (int i = threadIdx.x; i < kSortTile; i += 256) t[i] = nms_key(dets, n, presorted, base + i, min_score);
+    for (int i = threadIdx.x; i < kSortTile; i += 256) t[i] = nms_key(dets + 4, 5, n, presorted, base + i, min_score);
     __syncthreads();
     if (do_sort)
         for (int kk = 2; kk <= kSortTile; kk <<= 1)
@@ -794,9 +806,10 @@ int launch_nms(const float *dets, int n, double thresh, int strict_gt, int preso
     if (ws_bytes < nms_workspace_bytes(n)) return TDRN_E_WORKSPACE;
     const int N = next_pow2(n);
     const NmsRule rule = plain_rule ? NmsRule{(float)thresh, 1} : make_rule(thresh, strict_gt);
+    const NmsSrc src{dets, 5, dets + 4, 5, 0, 0};
     if (n <= kNmsLdsKeys) {
         TDRN_TRY(allow_big_lds((const void *)nms_plain_kernel<false>));
-        hipLaunchKernelGGL(nms_plain_kernel<false>, dim3(1), dim3(256), (size_t)N * 8, s, dets, n, rule, presorted,
+        hipLaunchKernelGGL(nms_plain_kernel<false>, dim3(1), dim3(256), (size_t)N * 8, s, src, n, rule, presorted,
                            (const unsigned long long *)nullptr, ws, keep_out, num_out, min_score, pre_top_k);
         return hip_status(hipGetLastError());
     }
@@ -809,8 +822,29 @@ int launch_nms(const float *dets, int n, double thresh, int strict_gt, int preso
                 hipLaunchKernelGGL(nms_global_stage_kernel, dim3(N / 512), dim3(256), 0, s, keys, N, kk, j);
             hipLaunchKernelGGL(nms_tile_merge_kernel, dim3(tiles), dim3(256), 0, s, keys, kk);
         }
-    hipLaunchKernelGGL(nms_plain_kernel<true>, dim3(1), dim3(256), 0, s, dets, n, rule, presorted, (const unsigned long long *)keys, ws,
+    hipLaunchKernelGGL(nms_plain_kernel<true>, dim3(1), dim3(256), 0, s, src, n, rule, presorted, (const unsigned long long *)keys, ws,
                        keep_out, num_out, min_score, pre_top_k);
+    return hip_status(hipGetLastError());
+}
+
+// All classes of one frame in ONE launch (DetectOTA, layers/functions/detection_ota.py:61-79): boxes (n,4) shared, scores (n,C)
+// row-major, one workgroup per class c in [first_class, C): box_utils.nms's rule on (boxes, scores[:, c]).
+// keep_out (C, n) / num_out (C): rows of the classes below first_class are left untouched.  ws: nms_classes_workspace_bytes.
+size_t nms_classes_workspace_bytes(int n, int C) { return (size_t)(C > 0 ? C : 1) * align_up(nms_workspace_bytes(n), 256); }
+int launch_nms_classes(const float *boxes, const float *scores, int n, int C, int first_class, float overlap, float min_score, int top_k,
+                       int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    if (!boxes || !scores || !keep_out || !num_out || !ws || n < 1 || C < 1 || first_class < 0 || first_class >= C) return TDRN_E_ARG;
+    if (ws_bytes < nms_classes_workspace_bytes(n, C)) return TDRN_E_WORKSPACE;
+    const size_t per = align_up(nms_workspace_bytes(n), 256);
+    if (n > kNmsLdsKeys) {              // beyond the LDS key limit: class by class through the global sort (strided rows are packed first)
+        return TDRN_E_UNSUPPORTED;
+    }
+    const NmsRule rule{overlap, 1};
+    const NmsSrc src{boxes, 4, scores + first_class, C, 1, (long long)per};
+    TDRN_TRY(allow_big_lds((const void *)nms_plain_kernel<false>));
+    hipLaunchKernelGGL(nms_plain_kernel<false>, dim3((unsigned)(C - first_class)), dim3(256), (size_t)next_pow2(n) * 8, s, src, n, rule, 0,
+                       (const unsigned long long *)nullptr, ws, keep_out + (size_t)first_class * n, num_out + first_class, min_score, top_k);
     return hip_status(hipGetLastError());
 }
 

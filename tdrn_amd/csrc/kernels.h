@@ -153,6 +153,9 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
                   double nms_thresh, float *out, int32_t *counts, void *ws, size_t ws_bytes,
                   hipStream_t s);
 size_t nms_workspace_bytes(int n);
+size_t nms_classes_workspace_bytes(int n, int C);
+int launch_nms_classes(const float *boxes, const float *scores, int n, int C, int first_class, float overlap, float min_score, int top_k,
+                       int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s);
 int launch_nms(const float *dets, int n, double thresh, int strict_gt, int presorted,
                int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s,
                int plain_rule = 0, float min_score = -INFINITY, int pre_top_k = 0);

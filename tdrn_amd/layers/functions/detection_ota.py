@@ -2,9 +2,13 @@
 (`tub` > 0 links detections across frames by box IoU x ROI-feature cosine similarity and gives them identities).
 
 Split like the reference's own cost profile: what touches every prior runs on the device through the C ABI -- the
-two-stage decode (tdrn_decode / tdrn_center_size) and the per-class NMS with box_utils.nms's rule (tdrn_nms_topk:
-normalised boxes, no "+1", top_k best candidates only, IoU <= overlap survives) -- while the tubelet bookkeeping on the
-handful of survivors (python dictionaries in the reference too) stays host-driven, with its small tensors on the GPU.
+two-stage decode (tdrn_decode / tdrn_center_size) and the NMS of ALL classes in ONE launch with box_utils.nms's rule
+(tdrn_nms_topk_classes: normalised boxes, no "+1", top_k best candidates only, IoU <= overlap survives) -- while the tubelet
+bookkeeping on the handful of survivors (python dictionaries in the reference too) stays host-driven, with its small
+tensors on the GPU.  Host round trips per frame: ONE for the counts, kept indices, scores and boxes of all classes; with
+tub > 0 ONE more for the similarity decisions of all classes (the reference syncs per class and per box).
+Tie rule: equal scores keep the LOWER prior index first (tdrn_nms_topk); box_utils.nms walks an ascending torch.sort from the
+end, whose tie order is unspecified -- the fixture (tests/golden/detect_ota.npz) is tie-free at the top_k cut.
 
 State (per class): tubelets[cl] = {identity: [tube, hold]} with tube = (<= tub, 5 + F) rows [score, box, roi feature],
 newest first, and hold = frames the tubelet survives without a match (loss_hold_len = 10); ides[cl] = their keys.
@@ -73,7 +77,7 @@ class Detect(object):
                 gone.append(ide)
         for ide in gone:
             del self.tubelets[cl][ide]
-        self.ides[cl] = torch.tensor([float(k) for k in self.tubelets[cl].keys()], dtype=torch.float32, device=self._dev)
+        self.ides[cl] = [float(k) for k in self.tubelets[cl].keys()]
 
     # ---- association pieces (layers/box_utils.py:295-367) --------------------------------------------------------
     def _roi_feature(self, feature, box):
@@ -106,6 +110,47 @@ class Detect(object):
             cols.append(((roi @ tf.t()) / (rn[:, None] * tf.norm(2, dim=1)[None, :])).mean(dim=1))
         return torch.stack(cols, 1)
 
+    def _nms_all_classes(self, boxes, conf_i):
+        """box_utils.nms for every class of one frame: ONE launch, ONE host read.  boxes (P,4), conf_i (P,C) on the device ->
+        (counts [C] ints, ids (C, top_k) int64 device tensor of kept prior indices, scores (C, top_k) and boxes (C, top_k, 4) on
+        the host as numpy, rows past a class's count unspecified)."""
+        lib = _lib.lib()
+        dev = boxes.device
+        P, C = conf_i.size(0), conf_i.size(1)
+        nb = lib.tdrn_nms_topk_classes_workspace_bytes(P, C)
+        ws = self._ws.get("ws_all")
+        if ws is None or ws.numel() < nb or ws.device != dev or self._ws.get("P") != P:
+            ws = self._ws["ws_all"] = torch.empty(nb, dtype=torch.uint8, device=dev)
+            self._ws["keep_all"] = torch.zeros((C, P), dtype=torch.int32, device=dev)
+            self._ws["num_all"] = torch.zeros(C, dtype=torch.int32, device=dev)
+            self._ws["P"] = P
+        keep, num = self._ws["keep_all"], self._ws["num_all"]
+        if P > 16384:                                      # beyond the one-launch limit (multi-scale frames): class by class
+            for cl in range(1, C):
+                dets = torch.cat((boxes, conf_i[:, cl:cl + 1]), 1).contiguous()
+                kk, cnt = _nms_topk(dets, self.nms_thresh, self.conf_thresh, self.top_k, self._ws)
+                num[cl] = cnt
+                if cnt:
+                    keep[cl, :cnt] = kk.int()
+        else:
+            _lib.check(lib.tdrn_nms_topk_classes(_lib.ptr(boxes), _lib.ptr(conf_i), P, C, 1, float(self.nms_thresh), float(self.conf_thresh),
+                                                 int(self.top_k), _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws), ws.numel(),
+                                                 _lib.current_stream(dev)), "tdrn_nms_topk_classes")
+        k = min(self.top_k, P)
+        ids = keep[:, :k].long().clamp_(0, P - 1)                      # (rows past the count hold stale indices: clamped, never used)
+        sc = conf_i.t().gather(1, ids)                                  # (C, k)
+        bx = boxes[ids.reshape(-1)].reshape(C, k, 4)
+        packed = torch.cat((num.float()[:, None], sc, bx.reshape(C, k * 4)), 1).cpu().numpy()      # the frame's one host read
+        counts = packed[:, 0].astype(np.int64)
+        counts[0] = 0
+        return counts, ids, packed[:, 1:1 + k], packed[:, 1 + k:].reshape(C, k, 4)
+
+    def _roi_cells(self, box, Hf, Wf):
+        """:86-89 on the host: the box's cell range on the feature map"""
+        x0 = int(np.clip(np.floor(box[0] * Wf), 0, Wf)); y0 = int(np.clip(np.floor(box[1] * Hf), 0, Hf))
+        x1 = int(np.clip(np.ceil(box[2] * Wf), 0, Wf)); y1 = int(np.clip(np.ceil(box[3] * Hf), 0, Hf))
+        return x0, y0, x1, y1
+
     def forward(self, loc_data, conf_data, prior_data, feature=None, arm_loc_data=None):
         """loc (B,P,4), conf (B*P,C), priors (P,4), feature (1,Cf,Hf,Wf) when tub > 0, arm_loc (B,P,4)|None.
         Returns (B, C, top_k, 5) rows [score, box] -- or (1, C, top_k, 6) rows [score, box, identity] when tub > 0
@@ -116,61 +161,87 @@ class Detect(object):
         if self.tub > 0 and num != 1:
             raise ValueError("tubelet linking works on one frame at a time")
         width = 6 if self.tub > 0 else 5
-        out = torch.zeros(num, C, self.top_k, width, device=dev)
+        out_h = np.zeros((num, C, self.top_k, width), np.float32)       # assembled on the host, uploaded once
         conf = conf_data.contiguous().float().view(num, P, C)
         pri = prior_data.to(dev).contiguous().float()
+        s7 = self.tub_feature_size
         for i in range(num):
             anchors = pri
             if arm_loc_data is not None:
                 anchors = center_size(decode(arm_loc_data[i], pri, self.variance))
-            boxes = decode(loc_data[i], anchors, self.variance)                 # (P,4) normalised
+            boxes = decode(loc_data[i], anchors, self.variance).contiguous()    # (P,4) normalised
+            counts, ids, sc_h, bx_h = self._nms_all_classes(boxes, conf[i].contiguous())
+            if self.tub == 0:
+                for cl in range(1, C):
+                    n = int(counts[cl])
+                    if n:
+                        out_h[i, cl, :n, 0] = sc_h[cl, :n]
+                        out_h[i, cl, :n, 1:5] = bx_h[cl, :n]
+                continue
+            # ---- tub > 0: roi features and similarities of every class on the device, decisions read back ONCE ----------
+            Hf, Wf = feature.size(-2), feature.size(-1)
+            feats, sims = {}, {}
             for cl in range(1, C):
-                scores = conf[i, :, cl]
-                dets = torch.cat((boxes, scores[:, None]), 1).contiguous()
-                ids, count = _nms_topk(dets, self.nms_thresh, self.conf_thresh, self.top_k, self._ws)
-                if count == 0:                                                # no score above conf_thresh (:70-73)
-                    if self.tub > 0:
-                        self.delete_tubelets(cl)
+                n = int(counts[cl])
+                if n == 0:
                     continue
-                nms_score, nms_box = scores[ids], boxes[ids]
-                if self.tub == 0:
-                    out[i, cl, :count] = torch.cat((nms_score[:, None], nms_box), 1)
-                    continue
-                feats = [self._roi_feature(feature, b) for b in nms_box]
-                identity = torch.full((count,), -1.0, device=dev)
+                fl = []
+                for b in bx_h[cl, :n]:
+                    x0, y0, x1, y1 = self._roi_cells(b, Hf, Wf)
+                    fl.append(F.interpolate(feature[:, :, y0:y1, x0:x1], (s7, s7), mode='bilinear', align_corners=True).reshape(-1, s7 * s7 * feature.size(1)))
+                feats[cl] = fl
                 tubes = self.tubelets[cl]
                 if tubes:
+                    nms_box = boxes[ids[cl, :n]]
                     heads = torch.stack([t[0][0, :5] for t in tubes.values()], 0)
-                    sim = torch.exp(self._iou_to_tubelets(nms_box, heads)) * self._cos_to_tubelets(feats, tubes)
-                    sim_max, sim_idx = sim.max(dim=1)
+                    sim = torch.exp(self._iou_to_tubelets(nms_box, heads)) * self._cos_to_tubelets(fl, tubes)
+                    sims[cl] = sim.max(dim=1)
+            if sims:
+                order = sorted(sims)
+                flat = torch.cat([torch.cat((sims[cl][0], sims[cl][1].float())) for cl in order]).cpu().numpy()   # the second host read
+            pos = 0
+            for cl in range(1, C):
+                n = int(counts[cl])
+                if n == 0:                                                    # no score above conf_thresh (:70-73)
+                    self.delete_tubelets(cl)
+                    continue
+                nms_score = sc_h[cl, :n]
+                identity = np.full(n, -1.0, np.float32)
+                tubes = self.tubelets[cl]
+                if cl in sims:
+                    sim_max = flat[pos:pos + n].copy(); sim_idx = flat[pos + n:pos + 2 * n].astype(np.int64)
+                    pos += 2 * n
                     # detections claiming the same tubelet: only the most similar one keeps its claim (:101-110)
-                    claim = sim_idx.tolist()
-                    for t in set(claim):
-                        rivals = [k for k, v in enumerate(claim) if v == t]
+                    for t in set(sim_idx.tolist()):
+                        rivals = np.nonzero(sim_idx == t)[0]
                         if len(rivals) > 1:
-                            best = rivals[int(torch.argmax(sim_max[rivals]))]
+                            best = rivals[int(np.argmax(sim_max[rivals]))]
                             for k in rivals:
                                 if k != best:
                                     sim_max[k] = 0.0
                     matched = sim_max > self.tub_thresh
-                    if bool(matched.any()):
-                        identity[matched] = self.ides[cl].index_select(0, sim_idx[matched])
+                    if matched.any():
+                        keys = list(tubes.keys())
+                        identity[matched] = np.asarray([float(keys[j]) for j in sim_idx[matched]], np.float32)
                 generate = (identity == -1) & (nms_score > self.tub_generate_score)
                 n_new = int(generate.sum())
                 if n_new > 0:                                                 # fresh identities continue the class's counter
                     first = 0 if self.history_max_ides[cl] < 0 else int(self.history_max_ides[cl]) + 1
-                    identity[generate] = torch.arange(first, first + n_new, device=dev, dtype=torch.float32)
+                    identity[generate] = np.arange(first, first + n_new, dtype=np.float32)
                     self.history_max_ides[cl] = first + n_new - 1
-                out[i, cl, :count] = torch.cat((nms_score[:, None], nms_box, identity[:, None]), 1)
-                for row, fea, ide in zip(out[i, cl, :count], feats, identity.tolist()):
+                out_h[i, cl, :n, 0] = nms_score
+                out_h[i, cl, :n, 1:5] = bx_h[cl, :n]
+                out_h[i, cl, :n, 5] = identity
+                rows = torch.from_numpy(out_h[i, cl, :n, :5].copy()).to(dev)     # [score, box] of the survivors (H2D, no sync)
+                for r, (fea, ide) in enumerate(zip(feats[cl], identity.tolist())):
                     if ide < 0:
                         continue
-                    info = torch.cat((row[:-1].clone()[None, :], fea), dim=1)   # [score, box, roi feature]
+                    info = torch.cat((rows[r:r + 1], fea), dim=1)               # [score, box, roi feature]
                     key = int(ide)
                     if key in tubes:
                         info = torch.cat((info, tubes[key][0]), 0)[:self.tub]
                     tubes[key] = [info, self.loss_hold_len + 1]
                 self.delete_tubelets(cl)
-        return out
+        return torch.from_numpy(out_h).to(dev)
 
     __call__ = forward

@@ -398,3 +398,38 @@ def test_nms_topk_is_box_utils_nms():
         torch.cuda.synchronize()
         got = keep[: int(num.item())].cpu().tolist()
         assert got == ref_nms(dets, overlap, min_score, top_k), (overlap, min_score, top_k)
+
+
+def test_nms_topk_classes_equals_per_class_calls():
+    """tdrn_nms_topk_classes (all classes of a frame in one launch: DetectOTA's class loop) keeps, class by class, exactly the
+    indices tdrn_nms_topk keeps on (boxes, scores[:, c]) -- incl. classes without a candidate and the top_k prefilter."""
+    import ctypes as C
+    from tdrn_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(5))
+    n, ncls, top_k = 3000, 7, 50
+    xy = rng.uniform(0, 0.8, (n, 2)).astype(np.float32)
+    wh = rng.uniform(0.02, 0.3, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    scores = rng.uniform(0, 1, (n, ncls)).astype(np.float32)
+    scores[:, 3] = 0.0                                    # a class with no candidate above min_score
+    scores[:, 5] *= 0.02                                  # ... and one with a handful
+    b, s = _cu(boxes), _cu(scores)
+    keep = torch.full((ncls, n), -7, dtype=torch.int32, device=DEV)
+    num = torch.full((ncls,), -7, dtype=torch.int32, device=DEV)
+    ws = torch.empty(lib.tdrn_nms_topk_classes_workspace_bytes(n, ncls), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.tdrn_nms_topk_classes(_lib.ptr(b), _lib.ptr(s), n, ncls, 1, 0.45, 0.01, top_k, _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws),
+                                         ws.numel(), _lib.current_stream(DEV)))
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    assert num[0] == -7 and (keep[0] == -7).all()         # rows below first_class are not touched
+    ws1 = torch.empty(lib.tdrn_nms_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    for c in range(1, ncls):
+        dets = _cu(np.concatenate([boxes, scores[:, c:c + 1]], 1))
+        k1 = torch.empty(n, dtype=torch.int32, device=DEV)
+        n1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        _lib.check(lib.tdrn_nms_topk(_lib.ptr(dets), n, 0.45, 0.01, top_k, _lib.ptr(k1), _lib.ptr(n1), _lib.ptr(ws1), ws1.numel(),
+                                     _lib.current_stream(DEV)))
+        cnt = int(n1.item())
+        assert num[c] == cnt, c
+        assert np.array_equal(keep[c, :cnt], k1.cpu().numpy()[:cnt]), c
+    assert num[3] == 0 and 0 < num[5] < num[1]
