@@ -1,24 +1,21 @@
-OUT=gpurun_out/r03_pmc
+OUT=gpurun_out/r03_pmc2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-PM="--steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-modes --graph 0 --no-detect --reps 1"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PM > /dev/null 2> $OUT/pmc_sq.err
+PM="--steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 --no-detect --reps 1"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py $PM > /dev/null 2> $OUT/a.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py $PM > /dev/null 2> $OUT/b.err
 python3 - <<'PY'
 import csv, glob, collections
-f = glob.glob("gpurun_out/r03_pmc/pmc_sq/**/*counter_collection.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-# per dispatch: kernel name + counters; keep the LAST forward's conv dispatches
-agg = collections.OrderedDict()
-for r in rows:
-    k = r["Kernel_Name"]
-    if "conv3x3" not in k: continue
-    key = (r["Dispatch_Id"], k[:60])
-    agg.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
-items = list(agg.items())[-18:]
-for (d, k), c in items:
-    wc = c.get("SQ_WAVE_CYCLES", 0)
-    g = c.get("GRBM_GUI_ACTIVE", 1)
-    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g / 8 * 1024) if g else 0
-    print("%-8s %-60s mfma_busy %.3f wait_any %.2f wait_inst %.2f active %.2f ldsconf %.3f gui/8 %.0f" % (d, k, busy, c.get("SQ_WAIT_ANY", 0) / wc if wc else 0,
-          c.get("SQ_WAIT_INST_ANY", 0) / wc if wc else 0, c.get("SQ_ACTIVE_INST_ANY", 0) / wc if wc else 0, c.get("SQ_LDS_BANK_CONFLICT", 0) / (g / 8 * 256) if g else 0, g / 8))
+for sub in ("a", "b"):
+    f = glob.glob("gpurun_out/r03_pmc2/%s/**/*counter_collection.csv" % sub, recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    agg = collections.OrderedDict()
+    for r in rows:
+        k = r["Kernel_Name"]
+        if "conv3x3" not in k: continue
+        agg.setdefault((r["Dispatch_Id"], k[11:64]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    items = list(agg.items())[-18:]
+    for (d, k), c in items:
+        if "pp_kernel" in k or "128, 16" in k or "128, 32" in k:
+            print(d, k, " ".join("%s=%.3g" % (n.replace("SQ_", ""), v) for n, v in sorted(c.items())))
 PY
