@@ -272,6 +272,9 @@ TDRN_API int tdrn_net_profile(tdrn_net *net, int enable);
 TDRN_API int tdrn_net_kernel_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries);
 /* same accounting per launch of the last profiled forward (name = producing parameter / op kind) */
 TDRN_API int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries);
+/* the same launches as a timeline: start / end of every launch of the last profiled forward in ms after the first launch's
+ * start, and the stream lane it ran on (0 = the caller's stream); entry i corresponds to entry i of tdrn_net_op_stats */
+TDRN_API int tdrn_net_op_timeline(tdrn_net *net, float *start_ms, float *end_ms, int *lane, int max_entries);
 
 /* Test / debug access to the plan's internal activation tensors (NHWC, net dtype) after a
  * forward on the same workspace: tdrn_net_tensor_info names tensor `index` after the parameter

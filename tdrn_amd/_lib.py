@@ -87,6 +87,7 @@ _SIGS = {
     "tdrn_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "tdrn_net_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int]),
     "tdrn_net_op_stats": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int]),
+    "tdrn_net_op_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

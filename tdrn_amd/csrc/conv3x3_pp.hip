@@ -447,8 +447,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     // inside an item hands its own on.  Slab image = the accumulator registers as they stand: [wave][quad 0..31][lane] x 16 B,
     // every access a contiguous 1 KiB per wave.  Hand-off = cdna_hip_programming.md Guideline 16: plain stores, every storing
     // wave's vmcnt(0), workgroup barrier, ONE agent-scope release + vmcnt(0), relaxed agent flag store; the consumer polls
-    // relaxed (bounded), ONE agent-scope acquire + vmcnt(0), workgroup barrier, plain loads.  The flag words are zeroed by a
-    // memset node in front of every launch.  Each of the two routines contains ONE workgroup barrier.
+    // relaxed (bounded), ONE agent-scope acquire + vmcnt(0), workgroup barrier, plain loads.  A flag has one reader, which
+    // resets it: a launch that finds the flag words zero leaves them zero (ConvArgs::sk_flags_zero: net.hip zeroes them once
+    // per forward on a side lane; otherwise a memset node in front of the launch).  Each of the two routines contains ONE workgroup barrier.
     auto slab_of = [&](int wg) -> f32x4 * { return (f32x4 *)(p.sk_slab + ((size_t)wg * 8 + wave) * (32 * 64 * 4)) + opaque_lane(); };
     auto begin_acc = [&](int c0) {
         if (c0 == 0) {
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
                 unsigned spins = 0;
                 while (__hip_atomic_load(p.sk_flag + (my_wg - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 20))
                     __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(p.sk_flag + (my_wg - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (its only reader)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -773,7 +775,7 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
     if (a.sk_ws && conv_pp_sk_enabled() && grid == 256 && p.items > 256 && p.items % 256 != 0) {
         p.sk_flag = (unsigned *)a.sk_ws;
         p.sk_slab = (float *)((char *)a.sk_ws + 1024);
-        TDRN_HIP_TRY(hipMemsetAsync(p.sk_flag, 0, 1024, s));
+        if (!a.sk_flags_zero) TDRN_HIP_TRY(hipMemsetAsync(p.sk_flag, 0, 1024, s));
     }
 #define PP_LAUNCH(DT)                                                                                                  \
     do {                                                                                                               \

@@ -74,10 +74,12 @@ static int run_case(int B, int H, int W, int Cin, int Cout, int pool, int relu, 
         conv_pp_force(k ? 1 : 0);
         conv_pp_sk_force(k == 2 ? 1 : 0);
         a.sk_ws = k == 2 ? sk_ws : nullptr;
+        a.sk_flags_zero = false;                          // first launch: the launcher's own memset node
         a.out = (pool == 2) ? nullptr : dout[k];          // pool == 2: pooled output only (as the trunk does)
         rcs[k] = launch_conv3x3_patch(a, pool ? dpool[k] : nullptr, s);
         if (rcs[k] != TDRN_OK) break;
         CK(hipStreamSynchronize(s));
+        a.sk_flags_zero = true;                           // from here on every launch must leave the flag words zero itself
         for (int i = 0; i < 3; ++i) launch_conv3x3_patch(a, pool ? dpool[k] : nullptr, s);
         CK(hipEventRecord(e0, s));
         for (int i = 0; i < iters; ++i) launch_conv3x3_patch(a, pool ? dpool[k] : nullptr, s);
@@ -88,6 +90,12 @@ static int run_case(int B, int H, int W, int Cin, int Cout, int pool, int relu, 
         us[k] = ms * 1000.0 / iters;
     }
     int bad = 0;
+    {
+        unsigned flags[256];
+        CK(hipMemcpy(flags, sk_ws, sizeof(flags), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 256; ++i)
+            if (flags[i] && flags[i] != 0xFFFFFFFFu) { bad = 1; fprintf(stderr, "  chained-split flag %d left at %u\n", i, flags[i]); break; }
+    }
     if (rcs[0] == TDRN_OK && rcs[1] == TDRN_OK && rcs[2] == TDRN_OK) {
         std::vector<unsigned short> o0(n_out), o1(n_out);
         for (int k = 1; k < 3; ++k) {

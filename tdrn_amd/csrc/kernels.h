@@ -41,6 +41,7 @@ struct ConvArgs {
     int fuse_cout = 0;
     int max_wgs = 0;                // patch kernel: > 0 caps the persistent grid (a multiple of 8), leaving CUs to concurrent lanes
     void *sk_ws = nullptr;          // conv3x3_pp.hip: scratch of conv_pp_sk_bytes() for the chained split (one launch at a time), or null
+    bool sk_flags_zero = false;     // the first 1024 bytes of sk_ws are zero on entry (every launch leaves them zero): no memset node
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
 int conv_splitk_choice(const ConvArgs &a);          // 1 = no split

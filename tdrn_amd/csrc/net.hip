@@ -133,7 +133,7 @@ struct tdrn_net {
     int plan_error = TDRN_OK;
     int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_zero = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_zero = nullptr, ev_skz = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
     std::vector<int> tensor_lane;
     std::vector<char> tensor_shared;
@@ -739,6 +739,7 @@ struct tdrn_net {
         }
         TDRN_TRY(pool::get_event(&ev_fork));
         TDRN_TRY(pool::get_event(&ev_zero));
+        TDRN_TRY(pool::get_event(&ev_skz));
         tensor_ev.assign(tensors.size(), nullptr);
         for (size_t t = 0; t < tensors.size(); ++t)
             if (tensor_shared[t]) TDRN_TRY(pool::get_event(&tensor_ev[t]));
@@ -1009,6 +1010,23 @@ struct tdrn_net {
                 zeroed_early = true;
             }
         }
+        // the chained split's flag words (conv3x3_pp.hip) are zeroed ONCE per forward, off the critical path; every launch
+        // leaves them zero (the consumer of a flag resets it)
+        bool skz_pending = false;
+        if (ws_fixed) {
+            void *flags = (char *)ws + ws_per_sample * (size_t)B;
+            if (lanes) {
+                if (!lane_used[1]) {
+                    TDRN_HIP_TRY(hipStreamWaitEvent(side[0], ev_fork, 0));
+                    lane_used[1] = true;
+                }
+                TDRN_HIP_TRY(hipMemsetAsync(flags, 0, 1024, side[0]));
+                TDRN_HIP_TRY(hipEventRecord(ev_skz, side[0]));
+                skz_pending = true;
+            } else {
+                TDRN_HIP_TRY(hipMemsetAsync(flags, 0, 1024, s0));
+            }
+        }
         DeformArgs dargs[4];
         const void *ts_y[4] = {nullptr, nullptr, nullptr, nullptr};
         int ts_cs[4] = {0, 0, 0, 0};
@@ -1050,7 +1068,14 @@ struct tdrn_net {
                     a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                     a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
                     if (lane != 0) a.max_wgs = side_grid;
-                    if (o.lane == 0 && ws_fixed) a.sk_ws = (char *)ws + ws_per_sample * (size_t)B;
+                    if (o.lane == 0 && ws_fixed) {
+                        a.sk_ws = (char *)ws + ws_per_sample * (size_t)B;
+                        a.sk_flags_zero = true;
+                        if (skz_pending && pp_conv_supported(a)) {
+                            TDRN_HIP_TRY(hipStreamWaitEvent(s0, ev_skz, 0));
+                            skz_pending = false;
+                        }
+                    }
                     if ((int)oi == fuse_first) {
                         a.fuse_x = io->x; a.fuse_w = (const float *)(wb + ops[0].w_off); a.fuse_b = (const float *)(wb + ops[0].b_off);
                         a.fuse_cout = ops[0].Cout;
@@ -1262,6 +1287,7 @@ void tdrn_net_destroy(tdrn_net *net)
     }
     pool::put_event(net->ev_fork);
     pool::put_event(net->ev_zero);
+    pool::put_event(net->ev_skz);
     delete net;
 }
 
@@ -1375,6 +1401,19 @@ int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries)
                 k.bytes += net->ops[j].bytes * net->last_batch;
             }
         k.ms = ms;
+    }
+    return n;
+}
+
+int tdrn_net_op_timeline(tdrn_net *net, float *start_ms, float *end_ms, int *lane, int max_entries)
+{
+    if (!net || !start_ms || !end_ms || max_entries <= 0) return TDRN_E_ARG;
+    int n = 0;
+    for (size_t i = 0; i < net->ev_op.size() && n < max_entries; ++i, ++n) {
+        TDRN_HIP_TRY(hipEventSynchronize(net->ev[2 * i + 1]));
+        TDRN_HIP_TRY(hipEventElapsedTime(&start_ms[n], net->ev[0], net->ev[2 * i]));
+        TDRN_HIP_TRY(hipEventElapsedTime(&end_ms[n], net->ev[0], net->ev[2 * i + 1]));
+        if (lane) lane[n] = net->profile == 2 && net->use_lanes ? net->ops[net->ev_op[i]].lane : 0;
     }
     return n;
 }

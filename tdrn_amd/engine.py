@@ -185,6 +185,18 @@ class NetEngine(object):
             check(n)
         return [dict(name=arr[i].name.decode(), flops=arr[i].flops, bytes=arr[i].bytes, ms=arr[i].ms) for i in range(n)]
 
+    def op_timeline(self):
+        """op_stats() plus start / end (ms after the first launch's start) and stream lane of every launch"""
+        import ctypes as C
+        ops = self.op_stats()
+        st, en, ln = (C.c_float * 128)(), (C.c_float * 128)(), (C.c_int * 128)()
+        n = self.lib.tdrn_net_op_timeline(self.handle, st, en, ln, 128)
+        if n < 0:
+            check(n)
+        for i in range(min(n, len(ops))):
+            ops[i].update(start=st[i], end=en[i], lane=ln[i])
+        return ops
+
 
 class GraphedCall(object):
     """One hipGraph per (callable, input shapes): `fn(*inputs)` -- e.g. net forward + Detect of one batch size -- is
@@ -192,9 +204,14 @@ class GraphedCall(object):
     synchronises (include/tdrn_hip.h), the side-lane fork/join of tdrn_net_forward is made of events, so the whole
     step, ~55 launches on 4 streams, captures as is.  Inputs are copied into the captured input buffers before each
     replay (or pass the tensors returned by `.inputs` and fill them in place); the outputs are the captured output
-    tensors, overwritten by every replay."""
+    tensors, overwritten by every replay -- a caller that keeps a result across steps asks for `clone_outputs=True`
+    (or copies it itself, on the stream that replays).
+    What capture freezes: every host-side value `fn` reads.  Detect.forward with a CPU tensor or a list as `scale`
+    turns it into kernel arguments at capture, so a later change of that value is NOT seen by the replays; pass
+    per-call values as device tensors among the inputs.  Shapes and dtypes are checked on every call."""
 
-    def __init__(self, fn, *example_inputs, warmup=2):
+    def __init__(self, fn, *example_inputs, warmup=2, clone_outputs=False):
+        self.clone_outputs = clone_outputs
         self.inputs = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream(self.inputs[0].device)
         side.wait_stream(torch.cuda.current_stream(self.inputs[0].device))
@@ -208,8 +225,25 @@ class GraphedCall(object):
             self.outputs = fn(*self.inputs)
 
     def __call__(self, *inputs):
-        for dst, src in zip(self.inputs, inputs):
+        if len(inputs) != len(self.inputs):
+            raise ValueError("GraphedCall captured %d inputs, called with %d" % (len(self.inputs), len(inputs)))
+        for i, (dst, src) in enumerate(zip(self.inputs, inputs)):
+            if src.shape != dst.shape or src.dtype != dst.dtype or src.device != dst.device:
+                raise ValueError("GraphedCall input %d: captured %s %s on %s, got %s %s on %s (one graph per shape: build another)"
+                                 % (i, tuple(dst.shape), dst.dtype, dst.device, tuple(src.shape), src.dtype, src.device))
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
-        return self.outputs
+        if not self.clone_outputs:
+            return self.outputs
+        return _clone_tree(self.outputs)
+
+
+def _clone_tree(o):
+    if isinstance(o, torch.Tensor):
+        return o.clone()
+    if isinstance(o, dict):
+        return {k: _clone_tree(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_clone_tree(v) for v in o)
+    return o

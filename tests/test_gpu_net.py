@@ -192,6 +192,24 @@ def test_batch32_rows_equal_single_frame_runs():
         assert torch.equal(o1[2][0], offs[2][b])
 
 
+def test_batch192_rows_equal_single_frame_runs():
+    """Six times the batch the plan was made for (split-K and batch-minor tiles are planned at batch 32; at 192 the small
+    maps have enough tiles that a split-K slice of a border tile can have no live tap at all -- conv_igemm.hip's
+    3-stage path once went into its epilogue with that slice's LDS-DMA still in flight): every checked
+    frame equals its single-frame run bit for bit, in both 16-bit types."""
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    x = torch.from_numpy(synth.synth_frames(32, 320, seed=8)).to(DEV).repeat(6, 1, 1, 1)
+    x[100] = x[100].flip(-1)
+    for dtype in ("bf16", "fp16"):
+        net.set_compute_dtype(dtype)
+        arm, offs, odm, conf = net(x)
+        conf = conf.view(192, 6375, 21)
+        for b in (0, 100, 191):
+            a1, o1, d1, c1 = net(x[b:b + 1])
+            assert torch.equal(a1[0], arm[b]) and torch.equal(d1[0], odm[b]) and torch.equal(c1, conf[b])
+            assert torch.equal(o1[0][0], offs[0][b]) and torch.equal(o1[3][0], offs[3][b])
+
+
 def test_drn_mobilenet_fp32_matches_oracle():
     net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True))
     x = synth.synth_frames(2, 320, seed=11)
@@ -285,19 +303,23 @@ def test_config3_vggbn_512_fp16_batch16():
     assert np.array_equal(det[b][..., 0], mine[0][..., 0])
 
 
-def test_config4_drn_mobilenet_bf16_batch64():
-    """BASELINE config #4's per-GPU workload: dualrefinedet_mobilenet 320, batch 64, bf16 (the depthwise strip
-    kernel in its 16-bit form): batch rows == single-frame runs bit for bit, drift of one frame within the table."""
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_config4_drn_mobilenet_batch64(dtype):
+    """BASELINE config #4's per-GPU workload: dualrefinedet_mobilenet 320, batch 64.  The config names no dtype: the
+    deployment default for such configs is fp16 (same rate as bf16, 8x less drift: DESIGN.md "Which 16-bit type");
+    bf16 is run as well (the depthwise strip kernel in both 16-bit forms).  Batch rows == single-frame runs bit for
+    bit, drift of one frame within the table."""
     net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True))
-    net.bfloat16()
+    net.set_compute_dtype(dtype)
     x = torch.from_numpy(synth.synth_frames(64, 320, seed=35)).to(DEV)
     arm, odm, conf = _rows_equal_single_runs(net, x, (0, 33, 63))
     assert arm.shape == (64, 6375, 4) and conf.shape == (64 * 6375, 21)
-    _check_drift("dualrefinedet_mobilenet", "bf16", net, sd, synth.synth_frames(1, 320, seed=5))
+    _check_drift("dualrefinedet_mobilenet", dtype, net, sd, synth.synth_frames(1, 320, seed=5))
 
 
-def test_config5_trn_8_clips_of_4_frames():
-    """BASELINE config #5: the TRN temporal path on 8 clips x 4 frames (evaluate_trn.py:438-467 batched over clips):
+@pytest.mark.parametrize("dtype16", ["fp16", "bf16"])
+def test_config5_trn_8_clips_of_4_frames(dtype16):
+    """(the config names no dtype: fp16 is the deployment default, bf16 runs too)  BASELINE config #5: the TRN temporal path on 8 clips x 4 frames (evaluate_trn.py:438-467 batched over clips):
     key frame -> static net (loc maps) -> temporal net (offsets), the three following frames reuse the cached
     offsets.  Every clip's results are bit-identical to running that clip alone; the fp32 key-frame pass of one
     clip matches the oracle.  refinedet_vgg (the model the config names) at batch 8 likewise."""
@@ -314,9 +336,9 @@ def test_config5_trn_8_clips_of_4_frames():
         for f in range(1, 4):
             outs.append(temp(cl[:, f].contiguous(), offset_list=outs[0][2]))
         return s_loc, maps, outs
-    s_loc, maps, outs = run(clips, "bf16")
+    s_loc, maps, outs = run(clips, dtype16)
     for c in (0, 5, 7):
-        s1, m1, o1 = run(clips[c:c + 1], "bf16")
+        s1, m1, o1 = run(clips[c:c + 1], dtype16)
         assert torch.equal(s1[0], s_loc[c]) and torch.equal(m1[0][0], maps[0][c])
         for f in range(4):
             assert torch.equal(o1[f][0][0], outs[f][0][c]), (c, f)
@@ -336,7 +358,7 @@ def test_config5_trn_8_clips_of_4_frames():
     np.testing.assert_allclose(o1[1][0].cpu().numpy(), r1[0].numpy(), atol=2e-3, rtol=0)
     # refinedet_vgg, batch 8
     rd, _ = _build("refinedet_vgg", (320, 21, True, 1024, True, True))
-    rd.bfloat16()
+    rd.set_compute_dtype(dtype16)
     _rows_equal_single_runs(rd, clips[:, 0].contiguous(), (0, 4, 7))
 
 
@@ -569,6 +591,36 @@ def test_hipgraph_replay_equals_eager():
         torch.cuda.synchronize()
         for got, want in zip(out, e):
             assert torch.equal(got, want)
+    # one graph per shape: another batch size or dtype is refused, not silently run on stale buffers
+    with pytest.raises(ValueError):
+        g(xa[:2])
+    with pytest.raises(ValueError):
+        g(xa.double())
+    # clone_outputs: a result kept across replays is not overwritten by the next one
+    gc = GraphedCall(step, xa, clone_outputs=True)
+    keep = gc(xa)
+    gc(xb)
+    torch.cuda.synchronize()
+    for got, want in zip(keep, ea):
+        assert torch.equal(got, want)
+
+
+def test_fused_first_conv_at_a_batch_past_4gib_of_input():
+    """The fused first conv never reads the (B,H,W,64) conv1_1 tensor, so the 2^32-byte input limit of the patch kernel does
+    not apply to it (the planner decided from geometry only and a refused launch failed the whole forward):
+    ssd4scale_vgg at 512 px, batch 136 (136*512*512*64*2 B = 4.25 GiB of conv1_1 output never materialised) runs, and its
+    first frames equal a batch-2 run."""
+    net, _ = _build("ssd4scale_vgg", (512, 21, 1024, False, False))
+    net.set_compute_dtype("fp16")
+    x = torch.from_numpy(synth.synth_frames(2, 512, seed=91)).to(DEV)
+    big = x.repeat(68, 1, 1, 1)
+    small = [t.clone() if torch.is_tensor(t) else t for t in net(x)]
+    out = net(big)
+    torch.cuda.synchronize()
+    for u, v in zip(out, small):
+        if torch.is_tensor(u) and torch.is_tensor(v) and u.dim() > 0 and u.shape[0] == 136:
+            assert torch.equal(u[:2], v)
+            assert torch.equal(u[134:], v)
 
 
 @pytest.mark.parametrize("model,args", [("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True)), ("ssd4scale_vgg", (320, 21, 1024, False, False))])
