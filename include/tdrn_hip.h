@@ -203,12 +203,13 @@ typedef struct {
 /* Plan-shaping switches (tdrn_net_config.plan_flags).  Every one of them changes the launch plan only: outputs are
  * bit-identical with the bit set or clear, except TDRN_PLAN_NO_DEFORM_TS in the 16-bit modes (where the rounding of the
  * deformable heads sits differently; both stay inside the 16-bit drift bounds of tests/test_gpu_net.py).
- * The environment variables of the same names (TDRN_FUSE_FIRST=0, TDRN_LATE_SIDE=0|1|2, TDRN_STREAMS=1, TDRN_DEFORM_TS=0)
+ * The environment variables of the same names (TDRN_FUSE_FIRST=0, TDRN_LATE_SIDE=0|1|2, TDRN_STREAMS=1, TDRN_DEFORM_TS=0, TDRN_CHAIN=1)
  * are diagnostics overrides read when a plan is built; a set variable wins over the flag. */
 #define TDRN_PLAN_NO_FUSE_FIRST 1   /* keep the first conv a launch of its own (its output tensor is then materialised) */
 #define TDRN_PLAN_NO_LATE_SIDE  2   /* release the side-lane convs on their true inputs instead of behind conv5_3      */
 #define TDRN_PLAN_ONE_STREAM    4   /* no side lanes: every launch on the caller's stream                              */
 #define TDRN_PLAN_NO_DEFORM_TS  8   /* deformable heads as the fused gather kernel (no transform-then-sample)           */
+#define TDRN_PLAN_CHAIN         16  /* the small top-of-pyramid layers as ONE queue-driven launch (measured slower: off by default) */
 
 typedef struct tdrn_net tdrn_net;
 

@@ -27,7 +27,7 @@ class NetConfig(C.Structure):
                 ("dtype", C.c_int), ("use_refine", C.c_int), ("plan_flags", C.c_int), ("reserved", C.c_int * 4)]
 
 
-PLAN_NO_FUSE_FIRST, PLAN_NO_LATE_SIDE, PLAN_ONE_STREAM, PLAN_NO_DEFORM_TS = 1, 2, 4, 8      # tdrn_hip.h TDRN_PLAN_*
+PLAN_NO_FUSE_FIRST, PLAN_NO_LATE_SIDE, PLAN_ONE_STREAM, PLAN_NO_DEFORM_TS, PLAN_CHAIN = 1, 2, 4, 8, 16      # tdrn_hip.h TDRN_PLAN_*
 
 
 class NetIO(C.Structure):

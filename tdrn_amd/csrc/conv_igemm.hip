@@ -63,18 +63,68 @@ template <> struct Mma<float> {
     }
 };
 
+// COH = agent-coherent access (the `sc1` cache-policy bit: served by / written through to the memory side, past the XCD's own
+// L2): what conv_chain_kernel uses for every tensor one of its tasks writes and another -- possibly on another XCD -- reads,
+// instead of agent-scope fences (a fence writes back / invalidates a whole L2: with ~3000 tasks a launch that was 3x slower
+// than the launches it replaces and slowed every concurrent kernel by 3-5x).
+template <bool COH = false>
 __device__ __forceinline__ void glds16(const char *src, char *lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, COH ? 16 : 0);
+}
+template <bool COH>
+__device__ __forceinline__ void st8(void *p, uint2 v)
+{
+    if constexpr (COH) __hip_atomic_store((unsigned long long *)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *(uint2 *)p = v;
+}
+template <bool COH>
+__device__ __forceinline__ uint2 ld8(const void *p)
+{
+    if constexpr (COH) {
+        const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((unsigned)v, (unsigned)(v >> 32));
+    } else {
+        return *(const uint2 *)p;
+    }
+}
+template <bool COH>
+__device__ __forceinline__ void st16(void *p, const u32x4 &v)
+{
+    if constexpr (COH) {
+        st8<true>(p, make_uint2(v[0], v[1]));
+        st8<true>((char *)p + 8, make_uint2(v[2], v[3]));
+    } else {
+        *(u32x4 *)p = v;
+    }
+}
+template <bool COH>
+__device__ __forceinline__ u32x4 ld16(const void *p)
+{
+    if constexpr (COH) {
+        const uint2 a = ld8<true>(p), b = ld8<true>((const char *)p + 8);
+        return u32x4{a.x, a.y, b.x, b.y};
+    } else {
+        return *(const u32x4 *)p;
+    }
 }
 
 // BM = pixel tile, BN = cout tile, waves arranged WGM (pixels) x WGN (couts).
 // STAGES = 2: one K-step prefetched, vmcnt(0) + __syncthreads() per step (small problems, 2 blocks/CU).
 // STAGES = 3: LDS ring with TWO K-steps of LDS-DMA in flight across a raw s_barrier and a counted
 //             s_waitcnt vmcnt(N) -- one workgroup per CU, latency hidden by prefetch depth, not occupancy.
-template <typename DT, int BM, int BN, int WGM, int WGN, int STAGES>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvParams p)
+template <int BM, int BN, int STAGES>
+constexpr int igemm_lds_bytes()
+{
+    return (STAGES * (BM + BN) * 128 > BM * (BN * 4 + 16)) ? STAGES * (BM + BN) * 128 : BM * (BN * 4 + 16);
+}
+
+// One (pixel tile, cout tile) x K slice x phase of the GEMM: tile index `wg` (pixel-tile major), K slice `ky` of p.splits,
+// phase `z` of `nz`.  Called by conv_igemm_kernel (one tile per workgroup) and by conv_chain_kernel (a queue of tiles of
+// several dependent layers).  Every thread of the workgroup runs it; it contains workgroup barriers.
+template <typename DT, int BM, int BN, int WGM, int WGN, int STAGES, bool COH = false>
+__device__ __forceinline__ void igemm_tile(const ConvParams &p, const int wg, const int ky, const int z, const int nz, char *smem)
 {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int ES = elem_traits<DT>::bytes;
@@ -83,23 +133,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     constexpr int PA = BM / RPP, PB = BN / RPP;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int CS = BN * 4 + 16;          // fp32 C-tile row stride (bytes), padded
-    constexpr int LDS = (STAGES * STAGE > BM * CS) ? STAGES * STAGE : BM * CS;
+    constexpr int LDS = igemm_lds_bytes<BM, BN, STAGES>();
     constexpr int WP = BM / WGM / 32, WC = BN / WGN / 32;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(BM % RPP == 0 && BN % RPP == 0 && WP >= 1 && WC >= 1, "tile shape");
-    __shared__ __attribute__((aligned(16))) char smem[LDS];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = t >> 3;
     const int lc16 = ((t & 7) ^ ((lrow >> 1) & 7)) << 4;   // swizzled source chunk (bytes)
-    // XCD-aware remap (bijective): workgroups are dealt round-robin over the 8 XCDs, each with its
-    // own L2; give every XCD a contiguous run of tiles so that the cout-tile siblings of a pixel
-    // tile and neighbouring pixel tiles (shared 3x3 halo) hit the same L2.
-    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
-    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
     const int mt = wg / p.n_tiles, nt = wg - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int z = blockIdx.z;
     const char *wbase = p.w + (size_t)z * p.Npad * p.Ktot * ES;
     const long long obase = p.o_base + (z >> 1) * p.o_pr + (z & 1) * p.o_pc;
     const int HoWo = p.Ho * p.Wo;
@@ -154,7 +197,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
             const int hi = hi0[i] + dh, wi = wi0[i] + dw;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const size_t off = (size_t)(pbase[i] + (hi * p.W + wi) * p.Cin + c0) * ES + lc16;
-            glds16(ok ? p.in + off : p.zero, sb + BN * 128 + (i * RPP + wave * 8) * 128);
+            glds16<COH>(ok ? p.in + off : p.zero, sb + BN * 128 + (i * RPP + wave * 8) * 128);
         }
     };
     // taps that touch the image for at least one row of this tile (bit = tr*kw + tq); all ones without padding
@@ -220,7 +263,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
         // skipped: a frame's partial sums must not depend on the batch it travels in); inside it only the steps of
         // live taps run.  Position the (tap, channel) cursor at the first live step.
         const int per = p.splits > 1 ? (nk + p.splits - 1) / p.splits : nk;
-        const int ks0 = p.splits > 1 ? blockIdx.y * per : 0, ks1 = min(nk, ks0 + per);
+        const int ks0 = p.splits > 1 ? ky * per : 0, ks1 = min(nk, ks0 + per);
         const int cpt = p.Cin / CK;                  // K-steps per tap
         int live = 0, first = -1;
         for (int tap = ks0 / cpt; tap * cpt < ks1; ++tap) {
@@ -307,12 +350,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
     if (partial_out) {
         // raw fp32 partial tile -> slab [split][phase][m][Npad]; bias / residual / ReLU happen in the reduce kernel
         constexpr int CPR = BN / 4;
-        float *slab = p.partial + ((size_t)blockIdx.y * gridDim.z + z) * (size_t)p.M * p.Npad;
+        float *slab = p.partial + ((size_t)ky * nz + z) * (size_t)p.M * p.Npad;
         for (int idx = t; idx < BM * CPR; idx += NT) {
             const int row = idx / CPR, chn = idx - row * CPR;
             const int m = m0 + row;
             if (m >= p.M) continue;
-            *(f32x4 *)(slab + (size_t)m * p.Npad + n0 + chn * 4) = *(const f32x4 *)(smem + row * CS + chn * 16);
+            st16<COH>(slab + (size_t)m * p.Npad + n0 + chn * 4, *(const u32x4 *)(smem + row * CS + chn * 16));
         }
         return;
     }
@@ -368,7 +411,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
                 }
                 if (p.res) {
                     float rv[P16];
-                    unpack16<DT>(*(const u32x4 *)(p.res + eo * ES), rv);
+                    unpack16<DT>(ld16<COH>(p.res + eo * ES), rv);
 #pragma unroll
                     for (int j = 0; j < P16; ++j) v[j] += rv[j];
                 }
@@ -376,10 +419,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
 #pragma unroll
                     for (int j = 0; j < P16; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
-                *(u32x4 *)(p.out + eo * ES) = pack16<DT>(v);
+                st16<COH>(p.out + eo * ES, pack16<DT>(v));
             }
         }
     }
+}
+
+template <typename DT, int BM, int BN, int WGM, int WGN, int STAGES>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<BM, BN, STAGES>()];
+    // XCD-aware remap (bijective): workgroups are dealt round-robin over the 8 XCDs, each with its
+    // own L2; give every XCD a contiguous run of tiles so that the cout-tile siblings of a pixel
+    // tile and neighbouring pixel tiles (shared 3x3 halo) hit the same L2.
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+    igemm_tile<DT, BM, BN, WGM, WGN, STAGES>(p, wg, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, smem);
 }
 
 int conv_patch_enabled()
@@ -421,21 +476,23 @@ template <typename DT> static int launch_dt(const ConvParams &p, int phases, hip
 
 // split-K second pass: out = epilogue(sum_s partial[s]) with the same views / flags as the fused epilogue.
 // One thread = 4 consecutive channels of one pixel (16-B slab reads, 8/16-B stores).
-template <typename DT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, int phases)
+// elements [i0, i1) of the (phase, pixel, 4-channel group) index space, thread t of a 256-thread workgroup taking i0 + t,
+// i0 + t + step, ...
+template <typename DT, bool COH = false>
+__device__ __forceinline__ void splitk_reduce_range(const ConvParams &p, const int phases, const long long i0, const long long i1,
+                                                    const long long step)
 {
     constexpr int ES = elem_traits<DT>::bytes;
     const int C4 = (p.Cout + 3) / 4;
-    const long long total = (long long)phases * p.M * C4;
     const int HoWo = p.Ho * p.Wo;
     const size_t slab = (size_t)phases * p.M * p.Npad;        // floats per K slice
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    for (long long i = i0 + threadIdx.x; i < i1; i += step) {
         const int c = (int)(i % C4) * 4;
         const long long r = i / C4;
         const int m = (int)(r % p.M), z = (int)(r / p.M);
         const float *src = p.partial + ((size_t)z * p.M + m) * p.Npad + c;
         f32x4 v = *(const f32x4 *)(p.bias + c);
-        for (int sidx = 0; sidx < p.splits; ++sidx) v += *(const f32x4 *)(src + sidx * slab);
+        for (int sidx = 0; sidx < p.splits; ++sidx) v += __builtin_bit_cast(f32x4, ld16<COH>(src + sidx * slab));
         long long eo;
         if (p.out_linear && !p.batch_minor) {
             eo = p.o_base + (long long)m * p.o_cs + c;
@@ -450,10 +507,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
         if (!p.out_f32 && full) {                     // NHWC tensor in the net dtype: channel counts are multiples of 8
             if (p.res) {
                 if constexpr (ES == 4) {
-                    const f32x4 rv = *(const f32x4 *)(p.res + eo * 4);
+                    const f32x4 rv = __builtin_bit_cast(f32x4, ld16<COH>(p.res + eo * 4));
                     v += rv;
                 } else {
-                    const uint2 rv = *(const uint2 *)(p.res + eo * 2);
+                    const uint2 rv = ld8<COH>(p.res + eo * 2);
                     DT t0{(unsigned short)(rv.x & 0xffffu)}, t1{(unsigned short)(rv.x >> 16)}, t2{(unsigned short)(rv.y & 0xffffu)}, t3{(unsigned short)(rv.y >> 16)};
                     v[0] += to_f32<DT>(t0); v[1] += to_f32<DT>(t1); v[2] += to_f32<DT>(t2); v[3] += to_f32<DT>(t3);
                 }
@@ -463,10 +520,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
             if constexpr (ES == 4) {
-                *(f32x4 *)(p.out + eo * 4) = v;
+                st16<COH>(p.out + eo * 4, __builtin_bit_cast(u32x4, v));
             } else {
                 const unsigned lo = pack2<DT>(v[0], v[1]), hi = pack2<DT>(v[2], v[3]);
-                *(uint2 *)(p.out + eo * 2) = make_uint2(lo, hi);
+                st8<COH>(p.out + eo * 2, make_uint2(lo, hi));
             }
             continue;
         }
@@ -480,6 +537,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, 
             else *(DT *)(p.out + (eo + j) * ES) = from_f32<DT>(x);
         }
     }
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p, int phases)
+{
+    const long long total = (long long)phases * p.M * ((p.Cout + 3) / 4);
+    splitk_reduce_range<DT>(p, phases, (long long)blockIdx.x * 256, total, (long long)gridDim.x * 256);
 }
 
 // number of K slices for a small-M problem: fill the chip (~2 workgroups per CU) but keep >= 4 K-steps each
@@ -504,7 +568,8 @@ size_t conv_splitk_bytes(const ConvArgs &a, int splits)
     return splits > 1 ? (size_t)splits * a.phases * a.B * a.Ho * a.Wo * a.Npad * sizeof(float) : 0;
 }
 
-int launch_conv(const ConvArgs &a, hipStream_t s)
+// ConvArgs -> the kernels' parameter block (validation included)
+static int make_params(const ConvArgs &a, ConvParams &p)
 {
     if (!a.in || !a.w || !a.out || !a.bias || !a.zero_page) return TDRN_E_ARG;
     const int es = dtype_bytes(a.dtype);
@@ -513,7 +578,6 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     if (a.phases != 1 && a.phases != 4) return TDRN_E_ARG;
     if (!a.out_f32 && (a.Cout % (16 / es) != 0)) return TDRN_E_UNSUPPORTED;
     if ((long long)a.B * a.H * a.W * a.Cin >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
-    ConvParams p;
     p.in = (const char *)a.in;
     p.w = (const char *)a.w;
     p.res = (const char *)a.res;
@@ -542,6 +606,13 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
+    return TDRN_OK;
+}
+
+int launch_conv(const ConvArgs &a, hipStream_t s)
+{
+    ConvParams p;
+    TDRN_TRY(make_params(a, p));
     if (p.M <= 0) return TDRN_OK;
     // 3x3/s1/p1 layers with enough tiles go to the warp-specialised patch kernel (TDRN_CONV_PATCH=0: off)
     static int use_patch = -1;
@@ -564,6 +635,175 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
         case TDRN_F32: hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, dim3(256), 0, s, p, a.phases); break;
         case TDRN_BF16: hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), grid, dim3(256), 0, s, p, a.phases); break;
         case TDRN_F16: hipLaunchKernelGGL((splitk_reduce_kernel<f16_t>), grid, dim3(256), 0, s, p, a.phases); break;
+    }
+    return hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_chain: several small, mutually dependent layers in ONE launch.
+//
+// The top of the pyramid (conv7's successors: extras, the last TCB level, its up-sampling, the 10x10 lateral) is a chain of
+// layers with 0.4-15 GFLOP each at batch 32: as launches each costs 18-40 us of launch + split-K reduce + dependency
+// latency for ~5 us of arithmetic, and they sit on the step's critical path.  Here every layer is a STAGE whose tiles
+// (igemm_tile: the same code and the same K order as the stand-alone launch, so every output bit is the same) and split-K
+// reduce ranges are TASKS in one queue, ordered so that a task depends only on earlier tasks.  A workgroup takes the next
+// task with an atomic counter, waits until the stages it depends on are complete (per-stage completion counters,
+// agent-scope acquire), runs it, and signals (agent-scope release).  Because a task is only ever taken by a RUNNING
+// workgroup and waits only for tasks taken before it, the launch cannot deadlock however few of its workgroups are resident
+// (persistent convs of other stream lanes may hold most CUs).  Independent stages (the lateral of the 10x10 level beside the
+// 5x5 chain) overlap by themselves.
+//
+// MEASURED, AND NOT THE DEFAULT PLAN (opt-in: TDRN_PLAN_CHAIN / TDRN_CHAIN=1).  Nine layers, ~3200 tasks at batch 32, bit-identical
+// to the nine launches (tested): 664 us alone / 717 us in the step with coherent (`sc1`) accesses for everything a task hands
+// to another, 806 us with plain accesses + one agent-scope release and acquire per task (which also slowed every concurrent
+// kernel 3-5x: each release writes an XCD's L2 back) -- against 170 us alone / 270 us in the step for the launches it
+// replaces.  A hand-off between workgroups costs what a kernel boundary costs on this chip (per-XCD L2s are not coherent
+// with each other and a CU's L1 is never refreshed by another CU's stores, MI355X_MICROARCH.md "splitk-seam": 5-13 us per seam),
+// `sc1` loads pay the memory-side latency on every K step of a 2-stage pipeline, and each task adds two atomic round trips.
+// profiles/r03_experiments.md has the timeline.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChainMax = 12;
+constexpr int kChainRedPerTask = 1024;          // (phase, pixel, 4-channel) elements per reduce task
+struct ChainStage {
+    ConvParams p;
+    int phases, tiles, gemm_tasks, red_tasks, task0, dep0, dep1, pad_;
+};
+struct ChainParams {
+    int n, total;
+    unsigned *ctr;                              // [0] queue head, [1 + 2s] tiles done of stage s, [2 + 2s] reduce tasks done; zero on entry
+    ChainStage st[kChainMax];
+};
+static_assert(sizeof(ChainParams) <= 4096, "kernel argument block");
+
+// One agent-scope atomic add issued by lane 0 only, with NO lane-divergent control flow for the compiler to structurize: the
+// exec mask is narrowed inside the asm block.  (A first version used `if (threadIdx.x == 0)` around the queue fetch at the top
+// and the completion signal at the bottom of the task loop; hipcc's loop structurizer let lanes 1..63 of wave 0 run on into the
+// next iteration's barrier while lane 0 was parked until "the others leave the loop" -- the fetch never happened and every
+// workgroup repeated its first task forever.  Everything in the loop below is wave-uniform.)
+__device__ __forceinline__ unsigned lane0_atomic_add(unsigned *p, unsigned v)
+{
+    unsigned old, zero = 0u;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(old), "=&s"(save)
+                 : "v"(zero), "v"(v), "s"(p)
+                 : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void conv_chain_kernel(const ChainParams cp)
+{
+    __shared__ __attribute__((aligned(16))) char smem[igemm_lds_bytes<128, 128, 2>()];
+    __shared__ int s_task;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // wave 0, all lanes (the same address: one request): poll until *c >= n.  Bounded: a wait that runs out -- it never should --
+    // is counted in ctr[40] and its task kept in ctr[41] for the host to see.
+    auto wait_for = [&](const unsigned *c, unsigned n, int task) {
+        unsigned spins = 0;
+        while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < n) {
+            if (++spins >= (1u << 18)) {
+                (void)lane0_atomic_add(cp.ctr + 40, 1u);
+                (void)lane0_atomic_add(cp.ctr + 41, (unsigned)task);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    };
+    int done_word = -1;                                         // completion counter of the task just finished
+    for (;;) {
+        if (wave == 0) {
+            if (done_word >= 0) (void)lane0_atomic_add(cp.ctr + done_word, 1u);   // (every wave's coherent stores had left before the barrier)
+            const int next = (int)lane0_atomic_add(cp.ctr, 1u);
+            s_task = next;                                      // (all lanes store the same value)
+        }
+        __syncthreads();
+        const int task = __builtin_amdgcn_readfirstlane(s_task);
+        if (task >= cp.total) return;
+        int s = 0;
+        while (s + 1 < cp.n && task >= cp.st[s + 1].task0) ++s;
+        s = __builtin_amdgcn_readfirstlane(s);
+        const ChainStage &st = cp.st[s];
+        const int local = task - st.task0;
+        const bool red = local >= st.gemm_tasks;
+        if (wave == 0) {
+            if (red) {
+                wait_for(cp.ctr + 1 + 2 * s, (unsigned)st.gemm_tasks, task);
+            } else {
+                for (int k = 0; k < 2; ++k) {
+                    const int d = k ? st.dep1 : st.dep0;
+                    if (d < 0) continue;
+                    if (cp.st[d].red_tasks) wait_for(cp.ctr + 2 + 2 * d, (unsigned)cp.st[d].red_tasks, task);
+                    else wait_for(cp.ctr + 1 + 2 * d, (unsigned)cp.st[d].gemm_tasks, task);
+                }
+            }
+        }
+        __syncthreads();
+        if (!red) {
+            const int per_z = st.tiles * st.p.splits;
+            const int z = local / per_z, r = local - z * per_z;
+            const int ky = r / st.tiles, wg = r - ky * st.tiles;
+            igemm_tile<DT, 128, 128, 2, 2, 2, true>(st.p, wg, ky, z, st.phases, smem);
+        } else {
+            const long long total = (long long)st.phases * st.p.M * ((st.p.Cout + 3) / 4);
+            const long long i0 = (long long)(local - st.gemm_tasks) * kChainRedPerTask;
+            const long long i1 = i0 + kChainRedPerTask < total ? i0 + kChainRedPerTask : total;
+            splitk_reduce_range<DT, true>(st.p, st.phases, i0, i1, 256);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+        __syncthreads();
+        done_word = (red ? 2 : 1) + 2 * s;                         // signalled by wave 0 at the top of the next round
+    }
+}
+
+size_t conv_chain_ctr_bytes() { return 256; }    // 1 + 2 * kChainMax counters, two diagnostic words at [40], [41]
+int conv_chain_max_layers() { return kChainMax; }
+
+int conv_chain_supported(const ConvArgs &a)
+{
+    if (a.out_f32 || a.fuse_x || a.Npad % 128 != 0) return 0;
+    if (a.splitk == 1 && conv_patch_enabled() && patch_conv_supported(a) && a.H * a.W >= conv_patch_enabled() * 400) return 0;   // the patch kernels' layer
+    return 1;
+}
+
+int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s)
+{
+    if (!layers || n <= 0 || n > kChainMax || !ctr) return TDRN_E_ARG;
+    ChainParams cp;
+    cp.n = n;
+    cp.ctr = ctr;
+    int task0 = 0;
+    const int dtype = layers[0].a.dtype;
+    for (int i = 0; i < n; ++i) {
+        const ConvArgs &a = layers[i].a;
+        if (a.dtype != dtype || !conv_chain_supported(a)) return TDRN_E_UNSUPPORTED;
+        ChainStage &st = cp.st[i];
+        TDRN_TRY(make_params(a, st.p));
+        st.p.n_tiles = a.Npad / 128;
+        st.phases = a.phases;
+        st.tiles = cdiv(st.p.M, 128) * st.p.n_tiles;
+        st.gemm_tasks = st.tiles * st.p.splits * a.phases;
+        const long long red_total = (long long)a.phases * st.p.M * ((st.p.Cout + 3) / 4);
+        st.red_tasks = st.p.splits > 1 ? (int)((red_total + kChainRedPerTask - 1) / kChainRedPerTask) : 0;
+        st.task0 = task0;
+        st.dep0 = layers[i].dep[0];
+        st.dep1 = layers[i].dep[1];
+        if (st.dep0 >= i || st.dep1 >= i) return TDRN_E_ARG;      // a stage may only depend on earlier stages
+        st.pad_ = 0;
+        task0 += st.gemm_tasks + st.red_tasks;
+    }
+    cp.total = task0;
+    if (cp.total <= 0) return TDRN_OK;
+    const int grid = cp.total < 512 ? cp.total : 512;             // two 66-KiB workgroups per CU
+    switch (dtype) {
+        case TDRN_F32: hipLaunchKernelGGL((conv_chain_kernel<float>), dim3(grid), dim3(256), 0, s, cp); break;
+        case TDRN_BF16: hipLaunchKernelGGL((conv_chain_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, cp); break;
+        case TDRN_F16: hipLaunchKernelGGL((conv_chain_kernel<f16_t>), dim3(grid), dim3(256), 0, s, cp); break;
+        default: return TDRN_E_ARG;
     }
     return hip_status(hipGetLastError());
 }

@@ -44,6 +44,14 @@ struct ConvArgs {
     bool sk_flags_zero = false;     // the first 1024 bytes of sk_ws are zero on entry (every launch leaves them zero): no memset node
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
+// Several small dependent layers in ONE launch (conv_igemm.hip, conv_chain_kernel): layer i may depend on up to two EARLIER
+// layers of the list (dep = index or -1); everything else a layer reads must be complete when the launch starts.  Every layer
+// keeps its own splitk / partial slab.  `ctr`: conv_chain_ctr_bytes() of zeroed device words.  Output bits equal launch_conv's.
+struct ChainLayer { ConvArgs a; int dep[2] = {-1, -1}; };
+int conv_chain_supported(const ConvArgs &a);
+int conv_chain_max_layers();
+size_t conv_chain_ctr_bytes();
+int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s);
 int conv_splitk_choice(const ConvArgs &a);          // 1 = no split
 size_t conv_splitk_bytes(const ConvArgs &a, int splits);
 // warp-specialised 3x3/s1/p1 kernel (conv3x3_patch.hip); out_pool = optional fused MaxPool2d(2,2) output

@@ -7,6 +7,7 @@
 //   model/ssd4scale_mobile.py:9-140          build_ssd4scale_mobile()
 //   model/refinedet_vgg.py:27-219            build_refinedet_vgg()
 //   model/ssd4scale_vgg.py                   build_ssd4scale_vgg()
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,9 @@ struct Op {
     int lane = 0;                                          // HIP stream lane (0 = the caller's stream)
     int pool_t = -1;                                       // conv: fused MaxPool2d(2,2) output tensor (patch kernel)
     int splitk = 1;                                        // conv: K slices, fixed per layer at plan time
+    bool chain_tag = false;                                // conv: candidate for the one-launch chain of small top-of-pyramid layers
+    int chain = -1;                                        // ... its stage index in that launch (conv_igemm.hip conv_chain_kernel), or -1
+    size_t chain_partial = 0;                              // ... its split-K slab inside the chain's slab region (bytes per sample)
 };
 
 // Side-lane streams and no-timing events are POOLED per process instead of destroyed with their net: a hipGraph captured for
@@ -120,6 +124,7 @@ struct tdrn_net {
     // independent branches of the tail (TCB laterals, ARM heads) run on side streams; dependencies
     // between lanes are hipEvents on the producing tensor.  Created lazily at the first forward.
     static constexpr int kLanes = 4;
+    static constexpr size_t kTailCtl = 256;  // bytes of chain counters in front of the chained split's scratch (workspace tail)
     size_t splitk_off[kLanes] = {0, 0, 0, 0};   // per-lane split-K slab region (bytes per sample from workspace start)
     int cur_lane = 0;
     // Side-lane convs (TCB laterals, ARM heads, offset convs) are held back until conv5_3 has been computed: released on their
@@ -127,6 +132,9 @@ struct tdrn_net {
     // 0.24 ms; held back, they run beside conv6/conv7 and the small top-down layers instead (+1.4 % frames/s; held until fc7
     // or capped to 128..224 workgroups: no further gain).  TDRN_LATE_SIDE 0: off, 2: until fc7; TDRN_SIDE_GRID: the cap.
     int t_late = -1, t_late2 = -1;
+    std::vector<int> chain_ops;          // the chain launch's member ops in stage order (empty: no chain)
+    size_t chain_partial_off = 0;        // the chain's split-K slab region (bytes per sample from workspace start)
+    bool pp_sk_planned = false;          // some main-lane conv may use conv3x3_pp.hip's chained split
     int fuse_first = -1;                 // index of the conv whose patch loader computes the first conv itself (16-bit modes), or -1
     int late_side = 1, side_grid = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
@@ -435,21 +443,28 @@ struct tdrn_net {
     void tcb(const int src[4], bool bias, int odm[4])
     {
         int x = conv(src[3], "last_layer_trans.0", bias, "", 256, 3, 1, 1, 1, 1);
+        ops.back().chain_tag = true;
         x = conv(x, "last_layer_trans.2", bias, "", 256, 3, 1, 1, 1, 0);
+        ops.back().chain_tag = true;
         x = conv(x, "last_layer_trans.3", bias, "", 256, 3, 1, 1, 1, 0);
+        ops.back().chain_tag = true;
         odm[3] = x;
         int t[3];
         for (int s = 0; s < 3; ++s) {
             cur_lane = s == 0 ? 1 : 2;      // lateral branches are independent of the top-down chain
             const std::string n = "trans_layers." + std::to_string(s);
             const int a = conv(src[s], n + ".0", bias, "", 256, 3, 1, 1, 1, 1);
+            ops.back().chain_tag = s == 2;
             t[s] = conv(a, n + ".2", bias, "", 256, 3, 1, 1, 1, 0);
+            ops.back().chain_tag = s == 2;
         }
         cur_lane = 0;
         for (int i = 0; i < 3; ++i) {
             const int lvl = 2 - i;
             const int u = conv_transpose2(x, "up_layers." + std::to_string(i), bias, 256, t[lvl], 1);
+            ops.back().chain_tag = i == 0;
             x = conv(u, "latent_layers." + std::to_string(i), bias, "", 256, 3, 1, 1, 1, 1);
+            ops.back().chain_tag = i == 0;
             odm[lvl] = x;
         }
     }
@@ -494,12 +509,11 @@ struct tdrn_net {
     // extras of the VGG variants (dualrefinedet_vggbn.py:36-45, refinedet_vgg.py:47-56, ssd4scale_vgg.py:25-34)
     int vgg_extras(int fc7)
     {
-        if (cfg.bn) {
-            const int e = conv(fc7, "extras.0", true, "extras.1", 256, 1, 1, 0, 1, 1);
-            return conv(e, "extras.3", true, "extras.4", 512, 3, 2, 1, 1, 1);
-        }
-        const int e = conv(fc7, "extras.0", true, "", 256, 1, 1, 0, 1, 1);
-        return conv(e, "extras.2", true, "", 512, 3, 2, 1, 1, 1);
+        const int e = cfg.bn ? conv(fc7, "extras.0", true, "extras.1", 256, 1, 1, 0, 1, 1) : conv(fc7, "extras.0", true, "", 256, 1, 1, 0, 1, 1);
+        ops.back().chain_tag = true;
+        const int x = cfg.bn ? conv(e, "extras.3", true, "extras.4", 512, 3, 2, 1, 1, 1) : conv(e, "extras.2", true, "", 512, 3, 2, 1, 1, 1);
+        ops.back().chain_tag = true;
+        return x;
     }
 
     // RefineDet-VGG: same trunk / TCB, plain (non-deformable) ODM heads (model/refinedet_vgg.py:27-219).
@@ -691,17 +705,73 @@ struct tdrn_net {
                 a.res = o.res >= 0 ? (const void *)1 : nullptr;
                 if (o.splitk == 1 && conv_patch_enabled() && patch_conv_supported(a) && a.H * a.W >= conv_patch_enabled() * 400)
                     o.stat = ST_CONV3;
-                if (o.splitk > 1) {
-                    const size_t per_sample = align_up((size_t)o.splitk * o.phases * a.Ho * a.Wo * o.Npad * sizeof(float), 256);
-                    if (per_sample > lane_bytes[o.lane]) lane_bytes[o.lane] = per_sample;
+                if (o.chain_tag && !(o.out_kind == OUT_TENSOR && conv_chain_supported(a))) o.chain_tag = false;
+            }
+            // The chain launch: tagged layers whose inputs are chain members or exist before the first member starts (a layer
+            // the patch kernels take at this frame size, and everything behind it, stays an ordinary launch).  Members move to
+            // the main lane and get their own split-K slabs (stages overlap inside the launch).
+            chain_ops.clear();
+            {
+                const char *ce = getenv("TDRN_CHAIN");
+                const bool chain_on = ce ? atoi(ce) != 0 : (cfg.plan_flags & TDRN_PLAN_CHAIN) != 0;   // opt-in: it lost (conv_igemm.hip)
+                int first = -1;
+                for (size_t i = 0; i < ops.size() && chain_on; ++i) {
+                    Op &o = ops[i];
+                    if (o.kind != OP_CONV || !o.chain_tag || (int)chain_ops.size() == conv_chain_max_layers()) continue;
+                    bool ok = true;
+                    for (int t : {o.in, o.res}) {
+                        if (t < 0) continue;
+                        int prod = -1;
+                        for (size_t j = 0; j < ops.size(); ++j)
+                            if (ops[j].out == t || ops[j].pool_t == t) prod = (int)j;
+                        const bool member = prod >= 0 && ops[prod].chain >= 0;
+                        if (!member && first >= 0 && prod > first) ok = false;
+                    }
+                    if (!ok) continue;
+                    if (first < 0) first = (int)i;
+                    o.chain = (int)chain_ops.size();
+                    chain_ops.push_back((int)i);
+                }
+                if (chain_ops.size() < 3) {              // not worth a queue
+                    for (int i : chain_ops) ops[i].chain = -1;
+                    chain_ops.clear();
+                }
+                // Queue order = dependency level (a stage's tasks wait only for EARLIER stages), ties in plan order: the
+                // independent lateral convs of the level below then sit between the stages of the serial chain and fill the
+                // workgroups that would otherwise spin on the chain's next dependency.
+                std::vector<int> level(chain_ops.size(), 0);
+                for (size_t k = 0; k < chain_ops.size(); ++k)
+                    for (int t : {ops[chain_ops[k]].in, ops[chain_ops[k]].res})
+                        for (size_t j = 0; j < k; ++j)
+                            if (t >= 0 && ops[chain_ops[j]].out == t && level[j] + 1 > level[k]) level[k] = level[j] + 1;
+                std::vector<int> order(chain_ops.size());
+                for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
+                std::vector<int> sorted;
+                for (int k : order) sorted.push_back(chain_ops[k]);
+                chain_ops = sorted;
+                for (size_t k = 0; k < chain_ops.size(); ++k) ops[chain_ops[k]].chain = (int)k;
+            }
+            size_t chain_bytes = 0;
+            for (Op &o : ops) {
+                if (o.kind != OP_CONV || o.pool_t >= 0 || o.splitk <= 1) continue;
+                const size_t per_sample = align_up((size_t)o.splitk * o.phases * (o.hw >> 16) * (o.hw & 0xffff) * o.Npad * sizeof(float), 256);
+                if (o.chain >= 0) {
+                    o.chain_partial = chain_bytes;
+                    chain_bytes += per_sample;
+                } else if (per_sample > lane_bytes[o.lane]) {
+                    lane_bytes[o.lane] = per_sample;
                 }
             }
+            for (int i : chain_ops) ops[i].lane = 0;
+            chain_partial_off = ws_per_sample;
+            ws_per_sample += chain_bytes;
             if (const char *pd = getenv("TDRN_PLAN_DUMP")) {
                 if (atoi(pd))
                     for (const Op &o : ops)
                         if (o.kind == OP_CONV)
-                            fprintf(stderr, "plan: %-28s lane %d  %dx%d k%d s%d d%d  Cin %4d Cout %4d  splitk %d  %s\n", o.w.c_str(), o.lane,
-                                    o.hw >> 16, o.hw & 0xffff, o.k, o.stride, o.dil, o.Cin, o.Cout, o.splitk, o.stat == ST_CONV3 ? "patch" : "igemm");
+                            fprintf(stderr, "plan: %-28s lane %d  %dx%d k%d s%d d%d  Cin %4d Cout %4d  splitk %d  %s  chain %d\n", o.w.c_str(), o.lane,
+                                    o.hw >> 16, o.hw & 0xffff, o.k, o.stride, o.dil, o.Cin, o.Cout, o.splitk, o.stat == ST_CONV3 ? "patch" : "igemm", o.chain);
             }
             for (int l = 0; l < kLanes; ++l) {
                 splitk_off[l] = ws_per_sample;
@@ -709,10 +779,14 @@ struct tdrn_net {
             }
         }
         // conv3x3_pp.hip's chained split needs a slab per workgroup; only launches on the main lane use it (one at a time)
+        // Batch-independent tail of the workspace: [256 B: the chain launch's counters][1 KiB: the chained split's flag words]
+        // [its slabs]; the first 1280 bytes are zeroed once per forward.
         ws_fixed = 0;
+        pp_sk_planned = false;
         if (cfg.dtype != TDRN_F32)
             for (const Op &o : ops)
-                if (o.kind == OP_CONV && o.stat == ST_CONV3 && o.lane == 0 && o.Cin >= 256 && o.Npad % 256 == 0) ws_fixed = align_up(conv_pp_sk_bytes(), 256);
+                if (o.kind == OP_CONV && o.stat == ST_CONV3 && o.lane == 0 && o.Cin >= 256 && o.Npad % 256 == 0) pp_sk_planned = true;
+        if (pp_sk_planned || !chain_ops.empty()) ws_fixed = kTailCtl + (pp_sk_planned ? align_up(conv_pp_sk_bytes(), 256) : 1024);
         const char *e = getenv("TDRN_STREAMS");
         if (cfg.plan_flags & TDRN_PLAN_ONE_STREAM) use_lanes = false;
         if (e) use_lanes = atoi(e) > 1;
@@ -1013,20 +1087,51 @@ struct tdrn_net {
         // the chained split's flag words (conv3x3_pp.hip) are zeroed ONCE per forward, off the critical path; every launch
         // leaves them zero (the consumer of a flag resets it)
         bool skz_pending = false;
+        char *const tail = (char *)ws + ws_per_sample * (size_t)B;       // [kTailCtl: chain counters][chained split: 1 KiB flags, slabs]
         if (ws_fixed) {
-            void *flags = (char *)ws + ws_per_sample * (size_t)B;
             if (lanes) {
                 if (!lane_used[1]) {
                     TDRN_HIP_TRY(hipStreamWaitEvent(side[0], ev_fork, 0));
                     lane_used[1] = true;
                 }
-                TDRN_HIP_TRY(hipMemsetAsync(flags, 0, 1024, side[0]));
+                TDRN_HIP_TRY(hipMemsetAsync(tail, 0, kTailCtl + 1024, side[0]));
                 TDRN_HIP_TRY(hipEventRecord(ev_skz, side[0]));
                 skz_pending = true;
             } else {
-                TDRN_HIP_TRY(hipMemsetAsync(flags, 0, 1024, s0));
+                TDRN_HIP_TRY(hipMemsetAsync(tail, 0, kTailCtl + 1024, s0));
             }
         }
+        // ConvArgs of a conv op whose output is a workspace tensor or a head view
+        auto conv_args = [&](const Op &o, ConvArgs &a) {
+            const Tensor &ti = tensors[o.in];
+            a.in = tptr(ws, o.in, B); a.w = wb + o.w_off; a.bias = (const float *)(wb + o.b_off); a.zero_page = wb;
+            a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
+            a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
+            a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
+            if (o.out_kind == OUT_TENSOR) {
+                const Tensor &to = tensors[o.out];
+                a.out = tptr(ws, o.out, B);
+                if (o.res >= 0) a.res = tptr(ws, o.res, B);
+                a.o_cs = to.Cpad;
+                if (o.phases == 4) {
+                    a.o_bs = (long long)to.H * to.W * to.Cpad; a.o_rs = 2ll * to.W * to.Cpad; a.o_cs = 2ll * to.Cpad;
+                    a.o_pr = (long long)to.W * to.Cpad; a.o_pc = to.Cpad;
+                } else {
+                    a.o_bs = (long long)to.H * to.W * to.Cpad; a.o_rs = (long long)to.W * to.Cpad;
+                }
+            } else {
+                const int per = o.out_kind == OUT_CONF ? 3 * C : 12;     // channels per pixel
+                const int per_prior = o.out_kind == OUT_CONF ? C : 4;
+                float *base = o.out_kind == OUT_ARM_LOC ? io->arm_loc : (o.out_kind == OUT_ODM_LOC ? io->odm_loc : io->conf);
+                a.out = base; a.out_f32 = 1;
+                a.o_base = (long long)scale_off[o.scale] * per_prior;
+                a.o_bs = (long long)P * per_prior; a.o_rs = (long long)a.Wo * per; a.o_cs = per;
+            }
+            if (o.splitk > 1) {
+                a.splitk = o.splitk;
+                a.partial = o.chain >= 0 ? (char *)ws + (chain_partial_off + o.chain_partial) * (size_t)B : (char *)ws + splitk_off[o.lane] * (size_t)B;
+            }
+        };
         DeformArgs dargs[4];
         const void *ts_y[4] = {nullptr, nullptr, nullptr, nullptr};
         int ts_cs[4] = {0, 0, 0, 0};
@@ -1037,6 +1142,7 @@ struct tdrn_net {
             if (o.kind == OP_OFF_OUT && !io->offsets[o.scale]) skip = true;
             if (o.kind == OP_LOC_OUT && !io->loc_maps[o.scale]) skip = true;
             if (o.kind == OP_FIRST && fuse_first >= 0) skip = true;            // computed inside the next conv's patch loader
+            if (o.kind == OP_CONV && o.chain > 0) skip = true;                 // computed by the chain launch at its first member's place
             if (skip) continue;
             const int lane = lanes ? o.lane : 0;
             hipStream_t s = lane == 0 ? s0 : side[lane - 1];
@@ -1061,15 +1167,40 @@ struct tdrn_net {
                                            B, o.hw, o.stride, o.Cout, tensors[o.out].Cpad, o.relu, cfg.dtype, s);
                     break;
                 case OP_CONV: {
-                    const Tensor &ti = tensors[o.in];
+                    if (o.chain >= 0) {
+                        // the whole chain as ONE launch at its first member's place; the other members are skipped below
+                        ChainLayer cl[16];
+                        const int n = (int)chain_ops.size();
+                        for (int k = 0; k < n; ++k) {
+                            const Op &m = ops[chain_ops[k]];
+                            conv_args(m, cl[k].a);
+                            int nd = 0;
+                            for (int t : {m.in, m.res}) {
+                                if (t < 0) continue;
+                                int dep = -1;
+                                for (int j = 0; j < k; ++j)
+                                    if (ops[chain_ops[j]].out == t) dep = j;
+                                if (dep >= 0) cl[k].dep[nd++] = dep;
+                                else if (lanes && tensor_lane[t] != 0) TDRN_HIP_TRY(hipStreamWaitEvent(s, tensor_ev[t], 0));
+                            }
+                        }
+                        if (skz_pending) {
+                            TDRN_HIP_TRY(hipStreamWaitEvent(s0, ev_skz, 0));
+                            skz_pending = false;
+                        }
+                        rc = launch_conv_chain(cl, n, (unsigned *)tail, s);
+                        if (rc == TDRN_OK && lanes)
+                            for (int k = 1; k < n; ++k) {
+                                const int t = ops[chain_ops[k]].out;
+                                if (t >= 0 && tensor_shared[t]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[t], s));
+                            }
+                        break;
+                    }
                     ConvArgs a;
-                    a.in = tptr(ws, o.in, B); a.w = wb + o.w_off; a.bias = (const float *)(wb + o.b_off); a.zero_page = wb;
-                    a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
-                    a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
-                    a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
+                    conv_args(o, a);
                     if (lane != 0) a.max_wgs = side_grid;
-                    if (o.lane == 0 && ws_fixed) {
-                        a.sk_ws = (char *)ws + ws_per_sample * (size_t)B;
+                    if (o.lane == 0 && pp_sk_planned) {
+                        a.sk_ws = tail + kTailCtl;
                         a.sk_flags_zero = true;
                         if (skz_pending && pp_conv_supported(a)) {
                             TDRN_HIP_TRY(hipStreamWaitEvent(s0, ev_skz, 0));
@@ -1079,29 +1210,6 @@ struct tdrn_net {
                     if ((int)oi == fuse_first) {
                         a.fuse_x = io->x; a.fuse_w = (const float *)(wb + ops[0].w_off); a.fuse_b = (const float *)(wb + ops[0].b_off);
                         a.fuse_cout = ops[0].Cout;
-                    }
-                    if (o.out_kind == OUT_TENSOR) {
-                        const Tensor &to = tensors[o.out];
-                        a.out = tptr(ws, o.out, B);
-                        if (o.res >= 0) a.res = tptr(ws, o.res, B);
-                        a.o_cs = to.Cpad;
-                        if (o.phases == 4) {
-                            a.o_bs = (long long)to.H * to.W * to.Cpad; a.o_rs = 2ll * to.W * to.Cpad; a.o_cs = 2ll * to.Cpad;
-                            a.o_pr = (long long)to.W * to.Cpad; a.o_pc = to.Cpad;
-                        } else {
-                            a.o_bs = (long long)to.H * to.W * to.Cpad; a.o_rs = (long long)to.W * to.Cpad;
-                        }
-                    } else {
-                        const int per = o.out_kind == OUT_CONF ? 3 * C : 12;     // channels per pixel
-                        const int per_prior = o.out_kind == OUT_CONF ? C : 4;
-                        float *base = o.out_kind == OUT_ARM_LOC ? io->arm_loc : (o.out_kind == OUT_ODM_LOC ? io->odm_loc : io->conf);
-                        a.out = base; a.out_f32 = 1;
-                        a.o_base = (long long)scale_off[o.scale] * per_prior;
-                        a.o_bs = (long long)P * per_prior; a.o_rs = (long long)a.Wo * per; a.o_cs = per;
-                    }
-                    if (o.splitk > 1) {
-                        a.splitk = o.splitk;
-                        a.partial = (char *)ws + splitk_off[o.lane] * (size_t)B;
                     }
                     if (a.fuse_x && !(conv_patch_enabled() && patch_conv_supported(a) > 0)) {
                         // the fusion was planned from the layer geometry; should the patch kernel decline THIS launch (a limit
@@ -1241,7 +1349,7 @@ struct tdrn_net {
         }
         bool prev_deform = false;
         for (const Op &o : ops) {
-            if (!(o.kind == OP_DEFORM && prev_deform)) stats[o.stat].launches += 1;
+            if (!(o.kind == OP_DEFORM && prev_deform) && !(o.kind == OP_CONV && o.chain > 0)) stats[o.stat].launches += 1;
             prev_deform = o.kind == OP_DEFORM;
             stats[o.stat].flops += o.flops * last_batch;
             stats[o.stat].bytes += o.bytes * last_batch;
@@ -1391,10 +1499,16 @@ int tdrn_net_op_stats(tdrn_net *net, tdrn_kernel_stat *out, int max_entries)
         tdrn_kernel_stat &k = out[n++];
         memset(&k, 0, sizeof(k));
         std::string name = std::string(kStatNames[o.stat]) + ":" + (o.w.empty() ? (o.in >= 0 ? net->tensors[o.in].label : "") : o.w);
+        if (o.kind == OP_CONV && o.chain == 0) name = "conv_chain:" + o.w + "+" + std::to_string(net->chain_ops.size() - 1);
         strncpy(k.name, name.c_str(), sizeof(k.name) - 1);
         k.launches = 1;
         k.flops = o.flops * net->last_batch;
         k.bytes = o.bytes * net->last_batch;
+        if (o.kind == OP_CONV && o.chain == 0)      // one launch covers all members
+            for (size_t j = 1; j < net->chain_ops.size(); ++j) {
+                k.flops += net->ops[net->chain_ops[j]].flops * net->last_batch;
+                k.bytes += net->ops[net->chain_ops[j]].bytes * net->last_batch;
+            }
         if (o.kind == OP_DEFORM)   // one launch covers the preceding deform ops of the other pyramid levels
             for (int j = net->ev_op[i] - 1; j >= 0 && net->ops[j].kind == OP_DEFORM; --j) {
                 k.flops += net->ops[j].flops * net->last_batch;

@@ -660,6 +660,42 @@ def test_fused_first_conv_equals_two_launches(model, args, monkeypatch):
         assert "first_conv" not in names[0] and names[1][0] == "first_conv"
 
 
+def test_chain_launch_equals_one_launch_per_layer():
+    """Opt-in plan TDRN_PLAN_CHAIN: the small top-of-pyramid layers (extras, last TCB level, its up-sampling, the lateral of the
+    level below) as ONE launch -- a queue of tiles and split-K reduce ranges with per-stage completion counters
+    (conv_igemm.hip conv_chain_kernel; measured slower than the launches it replaces, hence opt-in).  Same tile code, same K
+    order, same split: every output is BIT-identical to the default plan, at batch 1 / 5 / 32, also when the inputs change
+    between forwards (a stale read of the previous forward's activations would show) and under repetition."""
+    model, args, size = "dualrefinedet_vggbn", (320, 21, 1024, 1, True, True), 320
+    for dtype in ("bf16", "fp32"):
+        chained, _ = _build(model, args)
+        chained.set_plan_flags(_lib.PLAN_CHAIN)
+        chained.set_compute_dtype(dtype)
+        plain, _ = _build(model, args)
+        plain.set_compute_dtype(dtype)
+        for batch in ((1, 5, 32) if dtype != "fp32" else (2,)):
+            for rep in range(3):
+                x = torch.from_numpy(synth.synth_frames(batch, size, seed=100 + 7 * rep + batch)).to(DEV)
+                a = chained(x)
+                b = plain(x)
+                for u, v in zip(a, b):
+                    if torch.is_tensor(u):
+                        assert torch.equal(u, v), (model, dtype, batch, rep)
+                    else:
+                        for uu, vv in zip(u, v):
+                            assert torch.equal(uu, vv), (model, dtype, batch, rep)
+        # (not vacuous: the chained plan has fewer launches, one of them the chain)
+        names = []
+        for net in (chained, plain):
+            eng = net._engine
+            eng.set_profile(1)
+            eng.forward(torch.from_numpy(synth.synth_frames(1, size, seed=3)).to(DEV))
+            torch.cuda.synchronize()
+            names.append([o["name"].split(":")[0] for o in eng.op_stats()])
+            eng.set_profile(0)
+        assert names[0].count("conv_chain") == 1 and "conv_chain" not in names[1] and len(names[0]) < len(names[1]) - 2
+
+
 def test_frame_stream_equals_unstreamed():
     """tdrn_amd.stream.FrameStream (per slot one hipGraph: copy-in of the next slot's pinned uint8 frames || preprocess -> net
     -> Detect -> copy-out; test_video.py:98-115 as a pipeline) returns, batch after batch, exactly what the same step gives
