@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r03_c
-timeout 3000 python -m pytest tests -x -q -m gpu > gpurun_out/r03_c/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/r03_c/pytest_gpu.txt
+timeout 2400 python -m pytest tests -x -q -m gpu --timeout 600 --durations=8 > gpurun_out/r03_c/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/r03_c/pytest_gpu.txt
 tail -25 gpurun_out/r03_c/pytest_gpu.txt
 timeout 900 python bench.py > gpurun_out/r03_c/bench.json 2> gpurun_out/r03_c/bench.err; echo "bench rc=$?"
 tail -3 gpurun_out/r03_c/bench.err
