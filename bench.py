@@ -431,12 +431,13 @@ def main():
     if world == 1 and NS == 1 and args.stream and not args.no_detect:
         import numpy as np
         from tdrn_amd.stream import FrameStream
-        fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NB)      # one pinned batch per slot: NB distinct batches cycle
+        NSL = max(3, NB)
+        fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NSL)     # one pinned batch per slot: the slots' batches cycle
         rng = np.random.RandomState(7)
-        for sl in range(NB):
+        for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
         fs.prime()
-        for k in range(2 * NB):
+        for k in range(2 * NSL):
             fs.run()
         fs.drain()
         t_stream = []
@@ -454,9 +455,10 @@ def main():
         want = fs.eager(fs.pinned_in(0).to(dev)).cpu()
         stream_blk = {"frames_per_s": round(B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
                       "vs_resident": round((B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
+                      "copy_streams_picked": (fs.calibration or {}).get("picked"),
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
-                      "per_step": "one hipGraph per slot: H2D %.1f MB of the NEXT batch's uint8 BGR 500x375 frames (pinned) || tdrn_preprocess, net, Detect, D2H %.1f MB of detections; %d slots"
-                                  % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NB),
+                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | caller's stream: one hipGraph per slot = tdrn_preprocess, net, Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
+                                  % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL),
                       "note": "the resident figure (`value`) starts from fp32 frames already preprocessed in HBM; this one includes the preprocess kernel and both copies"}
         del fs
 

@@ -5,24 +5,33 @@ the CPU -> .cuda() -> net -> Detect -> .cpu(); evaluate.py:452-461 the same from
 BGR frames travels H2D as uint8 (4x less than the fp32 tensor the reference uploads), is resized / mean-subtracted on the
 device (tdrn_preprocess), runs net + Detect, and only the (B, C, top_k, 5) detections travel back.
 
-One captured hipGraph per slot holds the WHOLE turn of the pipeline:
-    graph[s] = {  H2D of slot s+1's pinned frames -> its device buffer      (a branch of its own: the copy engine)
-               || tdrn_preprocess(slot s) -> net (~60 launches, 4 streams) -> Detect -> D2H of slot s's detections }
-so the copy-in of the NEXT batch runs under THIS batch's convolutions with the dependencies inside the graph.  (First
-version: copies on separate HIP streams chained to the step graphs by events -- measured with rocprofv3's memory-copy
-trace: the copy-in started 2.6 ms into a 3.1-ms step, whatever the host order, more streams or more slots, and the next
-step waited for it: 85-91 % of the resident rate.)
-Protocol: write batch k+1 into `pinned_in(next slot)` BEFORE `run()` launches batch k; `result(slot)` is batch k's output.
+Three queues, chained by events, `slots` (>= 3) buffers used cyclically:
+    copy-in stream :  H2D of batch k+2's pinned frames          (waits for the step that last read that slot's device buffer)
+    caller's stream:  hipGraph[slot] = tdrn_preprocess -> net (~60 launches on 4 lanes) -> Detect      (waits for its H2D)
+    copy-out stream:  D2H of batch k's detections               (waits for step k; step k + slots waits for it)
+Measured (bench.py `stream`, profiles/r03_experiments.md): 0.97 of the resident rate, given copy streams that do not share a
+hardware queue with a busy lane (see _pick_streams: chosen by a 0.3-s calibration at construction).  What did NOT work: the D2H on the
+step's own stream (a 2.7-MB device-to-pinned copy there is a blit kernel that queues behind the step and costs 0.54 ms:
+0.85 of resident -- that alone was the whole shortfall of the first versions); the H2D as a node of the step's graph (the
+executor ran it ~2.4 ms into the step, in series with Detect: 0.86-0.91); copying only one batch ahead (the copy then has
+to start and finish inside one step).
+Protocol: batches 0 and 1 go into pinned_in(0), pinned_in(1), then prime(); before every run() -- which launches the
+oldest batch not yet run -- the producer writes the batch TWO ahead of it into pinned_in(next_in()); result(slot) is
+that run's output.
 """
 import torch
 
 from .data import base_transform
 
+AHEAD = 2        # batches copied in ahead of the one being computed
+
 
 class FrameStream(object):
-    """slots x (pinned input, device input, captured turn, device output, pinned output), used cyclically."""
+    """slots x (pinned input, device input, captured step, device output, pinned output), used cyclically."""
 
-    def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=2):
+    def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=3, calibrate=True):
+        if slots < AHEAD + 1:
+            raise ValueError("FrameStream needs at least %d slots (it copies %d batches ahead)" % (AHEAD + 1, AHEAD))
         dev = engine.device
         self.dev, self.B, self.slots = dev, batch, slots
         H0, W0 = frame_hw
@@ -46,50 +55,102 @@ class FrameStream(object):
         torch.cuda.synchronize(dev)
         self.host_out = [torch.empty(tuple(probe.shape), dtype=probe.dtype).pin_memory() for _ in range(slots)]
         self.graphs, self.dev_out = [], []
-        self._copy_stream = torch.cuda.Stream(dev)
         for s in range(slots):
-            nxt = (s + 1) % slots
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                cur = torch.cuda.current_stream(dev)
-                self._copy_stream.wait_stream(cur)                      # fork: the next slot's frames
-                with torch.cuda.stream(self._copy_stream):
-                    self.dev_in[nxt].copy_(self.host_in[nxt], non_blocking=True)
                 out = one_step(self.dev_in[s])
-                self.host_out[s].copy_(out, non_blocking=True)
-                cur.wait_stream(self._copy_stream)                      # join
             self.graphs.append(g)
             self.dev_out.append(out)
-        self.ev_done = [torch.cuda.Event() for _ in range(slots)]
+        self._in_stream = torch.cuda.Stream(dev)
+        self._out_stream = torch.cuda.Stream(dev)
+        self.ev_in = [torch.cuda.Event() for _ in range(slots)]        # slot's frames are on the device
+        self.ev_step = [torch.cuda.Event() for _ in range(slots)]      # slot's step has run (its device input is free again)
+        self.ev_out = [torch.cuda.Event() for _ in range(slots)]       # slot's detections are on the host (its device output is free)
+        cur = torch.cuda.current_stream(dev)
+        for e in self.ev_in + self.ev_step + self.ev_out:
+            e.record(cur)
         self._k = 0
+        self.calibration = None
+        if calibrate:
+            self._pick_streams()
+
+    def _pick_streams(self, candidates=4, steps=10):
+        """ROCm maps HIP streams onto a few in-order hardware queues (4 by default) in creation order, and HIP does not say
+        which: a copy stream that shares the queue of the step's stream, or of a busy side lane of the net, has its event
+        waits -- and with them the copy -- held behind that lane's kernels (0.85 of the resident rate), one that shares an
+        idle lane's queue costs nothing (0.97); giving every stream a queue of its own (GPU_MAX_HW_QUEUES=8 / 16) is worse
+        still (0.65 / 0.52: the copies' blit kernels then really do run beside the convolutions).  So: a few candidate streams,
+        one short timed run of the pipeline per (copy-in, copy-out) pair, keep the best pair."""
+        import time
+        cands = [torch.cuda.Stream(self.dev) for _ in range(candidates)]
+        timings = {}
+        for i in range(candidates):
+            for j in range(candidates):
+                self._in_stream, self._out_stream = cands[i], cands[j]
+                self.prime()
+                for _ in range(2):
+                    self.run()
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.run()
+                torch.cuda.synchronize(self.dev)
+                timings[(i, j)] = (time.perf_counter() - t0) / steps
+        best = min(timings, key=timings.get)
+        self._in_stream, self._out_stream = cands[best[0]], cands[best[1]]
+        self.calibration = {"ms_per_step": {"%d,%d" % k: round(v * 1e3, 3) for k, v in timings.items()}, "picked": "%d,%d" % best}
+        self.prime()
 
     def eager(self, frames_u8_dev):
         """the same step without capture, slots or copies (for the bit-identity check)"""
         return self._fn(frames_u8_dev)
 
     def pinned_in(self, slot):
-        """the pinned (B,H,W,3) uint8 buffer a producer (decoder, camera) fills for `slot`"""
+        """the pinned (B,H,W,3) uint8 buffer a producer (decoder, camera) fills for `slot`; blocks until the last copy-in
+        that read it has finished"""
+        self.ev_in[slot].synchronize()
         return self.host_in[slot]
 
+    def next_in(self):
+        """the slot the producer has to fill before the next run(): the batch AHEAD of the one that run() will launch"""
+        return (self._k + AHEAD) % self.slots
+
+    def _copy_in(self, slot):
+        with torch.cuda.stream(self._in_stream):
+            self._in_stream.wait_event(self.ev_step[slot])      # the step that last read this device buffer has run
+            self._in_stream.wait_event(self.ev_out[slot])       # ... and its detections have left the slot's output buffer, so
+            self.dev_in[slot].copy_(self.host_in[slot], non_blocking=True)      # ev_in is all the slot's next step waits for
+            self.ev_in[slot].record(self._in_stream)
+
     def prime(self, frames=None):
-        """Before the first run(): slot 0's frames (already in pinned_in(0), or copied there from `frames`) go to the device."""
-        if frames is not None:
-            self.host_in[0].copy_(frames)
-        self.dev_in[0].copy_(self.host_in[0], non_blocking=True)
+        """Before the first run(): the first AHEAD batches (already in pinned_in(0..AHEAD-1), or copied there from the list
+        `frames`) go to the device."""
+        torch.cuda.synchronize(self.dev)
         self._k = 0
+        for s in range(AHEAD):
+            if frames is not None:
+                self.host_in[s].copy_(frames[s])
+            self._copy_in(s)
 
     def run(self):
-        """Launch the turn of the current slot (its frames were copied in by the previous turn, or by prime()); the NEXT
-        slot's pinned buffer must already hold the next batch.  Returns the slot; never blocks the host."""
+        """Queue: the copy-in of the batch in pinned_in(next_in()), the step of the oldest batch not yet run, the copy-out of
+        its detections.  Returns that step's slot; never blocks the host."""
         s = self._k % self.slots
+        self._copy_in((self._k + AHEAD) % self.slots)
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.ev_in[s])
         self.graphs[s].replay()
-        self.ev_done[s].record(torch.cuda.current_stream(self.dev))
+        self.ev_step[s].record(cur)
+        with torch.cuda.stream(self._out_stream):
+            self._out_stream.wait_event(self.ev_step[s])
+            self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
+            self.ev_out[s].record(self._out_stream)
         self._k += 1
         return s
 
     def result(self, slot):
-        """Detections of the batch last run in `slot`, on the host (blocks until its turn has finished)."""
-        self.ev_done[slot].synchronize()
+        """Detections of the batch last run in `slot`, on the host (blocks until they have arrived)."""
+        self.ev_out[slot].synchronize()
         return self.host_out[slot]
 
     def drain(self):

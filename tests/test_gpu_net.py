@@ -697,30 +697,36 @@ def test_chain_launch_equals_one_launch_per_layer():
 
 
 def test_frame_stream_equals_unstreamed():
-    """tdrn_amd.stream.FrameStream (per slot one hipGraph: copy-in of the next slot's pinned uint8 frames || preprocess -> net
-    -> Detect -> copy-out; test_video.py:98-115 as a pipeline) returns, batch after batch, exactly what the same step gives
-    without capture, slots or copies -- also when a slot's buffers are re-used turn after turn."""
+    """tdrn_amd.stream.FrameStream (copy-in stream two batches ahead | one hipGraph per slot: preprocess -> net -> Detect |
+    copy-out stream, chained by events; test_video.py:98-115 as a pipeline) returns, batch after batch, exactly what the same
+    step gives without capture, slots or copies -- also when a slot's buffers are re-used turn after turn and when the
+    producer hands over each batch only just in time."""
     from tdrn_amd.stream import FrameStream
     net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
     net.set_compute_dtype("fp16")
     eng = net.engine(DEV)
     pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
-    B, slots = 3, 2
+    B, slots, n = 3, 3, 8
     fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots)
     rng = np.random.RandomState(11)
-    feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)) for _ in range(5)]
-    fs.prime(feeds[0])
-    results = []
-    for k in range(5):                                     # batch k runs in slot k % 2; batch k+1 is handed over before the launch
-        if k + 1 < 5:
-            if k + 1 >= slots:
-                fs.result((k + 1) % slots)                 # (the turn that last used that slot's buffers has finished)
-            fs.pinned_in((k + 1) % slots).copy_(feeds[k + 1])
+    feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)) for _ in range(n)]
+    fs.prime(feeds[:2])
+    results, pending = [], []
+    for k in range(n):                                     # batch k runs in slot k % 3; batch k+2 is handed over before the launch
+        if k + 2 < n:
+            assert fs.next_in() == (k + 2) % slots
+            fs.pinned_in(fs.next_in()).copy_(feeds[k + 2])
         s = fs.run()
         assert s == k % slots
-        results.append(fs.result(s).clone())
+        pending.append(s)
+        if len(pending) == 2:                              # read results one step late, as a consumer overlapping with the device would
+            results.append(fs.result(pending.pop(0)).clone())
+    while pending:
+        results.append(fs.result(pending.pop(0)).clone())
     fs.drain()
     for k, got in enumerate(results):
         want = fs.eager(feeds[k].to(DEV)).cpu()
         assert torch.equal(got, want), k
     assert (results[0][..., 0] > 0).any()                  # (not vacuous: there are detections)
+    with pytest.raises(ValueError):
+        FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=2)
