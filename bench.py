@@ -402,31 +402,9 @@ def main():
     kernels = {s["name"]: {"ms": round(s["ms"], 4), "ms_single_stream": round(solo_ms.get(s["name"], 0.0), 4), "launches": s["launches"],
                            "gflop": round(s["flops"] / 1e9, 3), "gbyte": round(s["bytes"] / 1e9, 4)} for s in stats_prod}
 
-    # ---- the other precisions of the same workload, timed in this run (N = 1 only) -----------------------------------
-    modes = None
-    if world == 1 and NS == 1 and not args.no_modes:
-        modes = {}
-        for dtm in [d for d in ("fp16", "fp32", "bf16") if d != args.dtype]:
-            print("bench.py: timing the %s mode" % dtm, file=sys.stderr, flush=True)
-            net.set_compute_dtype(dtm)
-            e2 = net.engine(dev)
-            st2 = make_stepper(e2, Detect(21, 0, 200, 0.01, 0.45))
-            k_steps = max(5, min(args.steps, 10 if dtm == "fp32" else args.steps))
-            for k in range(3):
-                st2(k)
-            r2 = sorted(timed(st2, k_steps, 3))
-            t2 = r2[len(r2) // 2]
-            sp, _ = profiled(e2, 2)
-            c2 = conv_family(sp)
-            a2 = c2["flops"] / (c2["ms"] * 1e-3) / 1e12 if c2["ms"] > 0 else 0.0
-            modes[dtm] = {"frames_per_s": round(B * k_steps / t2, 2), "ms_per_step": round(t2 / k_steps * 1e3, 4), "steps": k_steps,
-                          "repetitions": 3, "forward_only_ms_per_step": round(forward_ms(e2), 4),
-                          "roofline": {"kernel": c2["name"], "achieved": round(a2, 2), "peak": PEAK_TFLOPS[dtm], "unit": "TFLOP/s",
-                                       "frac": round(a2 / PEAK_TFLOPS[dtm], 4)}}
-            del st2, e2
-        net.set_compute_dtype(args.dtype)
-
     # ---- the streamed mode: frames come from the host, detections go back (test_video.py:98-115 as a pipeline) -----------
+    # (before the other precisions' engines are created and destroyed: on ROCm 7.2 a hipGraph captured for the fp32 engine AFTER
+    # other engines' graphs and events had been destroyed crashed in hipGraphLaunch)
     stream_blk = None
     if world == 1 and NS == 1 and args.stream and not args.no_detect:
         import numpy as np
@@ -461,6 +439,30 @@ def main():
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL),
                       "note": "the resident figure (`value`) starts from fp32 frames already preprocessed in HBM; this one includes the preprocess kernel and both copies"}
         del fs
+
+    # ---- the other precisions of the same workload, timed in this run (N = 1 only) -----------------------------------
+    modes = None
+    if world == 1 and NS == 1 and not args.no_modes:
+        modes = {}
+        for dtm in [d for d in ("fp16", "fp32", "bf16") if d != args.dtype]:
+            print("bench.py: timing the %s mode" % dtm, file=sys.stderr, flush=True)
+            net.set_compute_dtype(dtm)
+            e2 = net.engine(dev)
+            st2 = make_stepper(e2, Detect(21, 0, 200, 0.01, 0.45))
+            k_steps = max(5, min(args.steps, 10 if dtm == "fp32" else args.steps))
+            for k in range(3):
+                st2(k)
+            r2 = sorted(timed(st2, k_steps, 3))
+            t2 = r2[len(r2) // 2]
+            sp, _ = profiled(e2, 2)
+            c2 = conv_family(sp)
+            a2 = c2["flops"] / (c2["ms"] * 1e-3) / 1e12 if c2["ms"] > 0 else 0.0
+            modes[dtm] = {"frames_per_s": round(B * k_steps / t2, 2), "ms_per_step": round(t2 / k_steps * 1e3, 4), "steps": k_steps,
+                          "repetitions": 3, "forward_only_ms_per_step": round(forward_ms(e2), 4),
+                          "roofline": {"kernel": c2["name"], "achieved": round(a2, 2), "peak": PEAK_TFLOPS[dtm], "unit": "TFLOP/s",
+                                       "frac": round(a2 / PEAK_TFLOPS[dtm], 4)}}
+            del st2, e2
+        net.set_compute_dtype(args.dtype)
 
     if rank == 0:
         line = {

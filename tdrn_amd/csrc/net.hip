@@ -74,6 +74,7 @@ namespace pool {
 std::mutex mu;
 std::vector<hipStream_t> streams;
 std::vector<hipEvent_t> events;
+std::vector<hipEvent_t> timing_events;
 int get_stream(hipStream_t *s)
 {
     {
@@ -90,6 +91,15 @@ int get_event(hipEvent_t *e)
     }
     return hip_status(hipEventCreateWithFlags(e, hipEventDisableTiming));
 }
+int get_timing_event(hipEvent_t *e)
+{
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!timing_events.empty()) { *e = timing_events.back(); timing_events.pop_back(); return TDRN_OK; }
+    }
+    return hip_status(hipEventCreate(e));
+}
+void put_timing_event(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); timing_events.push_back(e); } }
 void put_stream(hipStream_t s) { if (s) { std::lock_guard<std::mutex> g(mu); streams.push_back(s); } }
 void put_event(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); events.push_back(e); } }
 }  // namespace pool
@@ -1032,7 +1042,7 @@ struct tdrn_net {
         if (profile && ev.size() < 2 * ops.size()) {
             const size_t old = ev.size();
             ev.resize(2 * ops.size());
-            for (size_t i = old; i < ev.size(); ++i) TDRN_HIP_TRY(hipEventCreate(&ev[i]));
+            for (size_t i = old; i < ev.size(); ++i) TDRN_TRY(pool::get_timing_event(&ev[i]));
         }
         ev_stat.clear();
         ev_op.clear();
@@ -1387,7 +1397,7 @@ int tdrn_net_create(const tdrn_net_config *cfg, tdrn_net **out)
 void tdrn_net_destroy(tdrn_net *net)
 {
     if (!net) return;
-    for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);          // (timing events of the profiling passes: never captured)
+    for (hipEvent_t e : net->ev) pool::put_timing_event(e);         // (timing events of the profiling passes: never captured; pooled like the rest)
     for (hipEvent_t e : net->tensor_ev) pool::put_event(e);
     for (int i = 0; i < tdrn_net::kLanes - 1; ++i) {
         pool::put_event(net->ev_join[i]);
