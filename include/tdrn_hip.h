@@ -112,6 +112,19 @@ TDRN_API int tdrn_nms_topk_classes(const float *boxes, const float *scores, int 
                                    float overlap, float min_score, int top_k, int32_t *keep_out, int32_t *num_out,
                                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* DetectOTA's association arithmetic on the device (the reference does it with torch ops on the GPU; here it is two kernels).
+ * tdrn_roi_resample -- detection_ota.py:86-93: for box b the cell range [x0,x1) x [y0,y1) of the (C,H,W) fp32 feature map
+ *   (cells (n,4) int32 = x0,y0,x1,y1, computed by the caller as the reference does: floor / ceil of box * size, clipped) is resampled
+ *   to S x S with F.upsample(mode='bilinear', align_corners=True)'s arithmetic and flattened as (C,S,S): out (n, C*S*S) fp32.
+ * tdrn_ota_similarity -- detection_ota.py:95-99 with box_utils.IoU / cos_similarity (layers/box_utils.py:295-367):
+ *   sim[i][j] = exp(IoU(boxes[i], head_j)) * mean_r cos(roi[i], feature of row r of tubelet j); best[i] = max_j, arg[i] = its index.
+ *   rows (R, 5+F) fp32: the stored rows [score, x1,y1,x2,y2, feature] of all m tubelets back to back, a tubelet's newest row (its
+ *   head) first; row_off (m+1) int32: tubelet j = rows [row_off[j], row_off[j+1]).  No host round trip. */
+TDRN_API int tdrn_roi_resample(const float *feature, int C, int H, int W, const int32_t *cells, int n, int S, float *out,
+                               void *stream);
+TDRN_API int tdrn_ota_similarity(const float *boxes, const float *roi, int n, int F, const float *rows, const int32_t *row_off,
+                                 int m, float *best, int32_t *arg, void *stream);
+
 /* COMPAT twin of   void _nms(int* keep_out, int* num_out, const float* boxes_host,
  *     int boxes_num, int boxes_dim, float nms_overlap_thresh, int device_id)
  *                                                          utils/nms/gpu_nms.hpp:1-2

@@ -62,6 +62,9 @@ _SIGS = {
     "tdrn_nms_topk_classes_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "tdrn_nms_topk_classes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tdrn_roi_resample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tdrn_ota_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "tdrn_preprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "tdrn_detect_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "tdrn_detect": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_double, C.c_void_p,

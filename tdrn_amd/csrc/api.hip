@@ -134,6 +134,17 @@ int tdrn_nms_topk_classes(const float *boxes, const float *scores, int n, int nu
                               workspace_bytes, (hipStream_t)stream);
 }
 
+int tdrn_roi_resample(const float *feature, int C, int H, int W, const int32_t *cells, int n, int S, float *out, void *stream)
+{
+    return launch_roi_resample(feature, C, H, W, cells, n, S, out, (hipStream_t)stream);
+}
+
+int tdrn_ota_similarity(const float *boxes, const float *roi, int n, int F, const float *rows, const int32_t *row_off, int m, float *best,
+                        int32_t *arg, void *stream)
+{
+    return launch_ota_similarity(boxes, roi, n, F, rows, row_off, m, best, arg, (hipStream_t)stream);
+}
+
 int tdrn_gpu_nms_host(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
                       float nms_overlap_thresh, int device_id)
 {

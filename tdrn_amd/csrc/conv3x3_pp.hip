@@ -58,6 +58,7 @@ struct PPParams {
     int relu;
     int tiles_x, tiles_per_img;    // 2-D tiles
     int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
+    int n_major;                   // item = nt * m_tiles + mt (an XCD's contiguous item range then needs ONE cout tile's weights) instead of mt * n_tiles + nt
     int M;                         // B*H*W
     // chained split ("stream-K", see the kernel): fp32 accumulator slabs [workgroup][8 waves][32][64 lanes][4] and one flag
     // word per workgroup; null = whole items only
@@ -208,8 +209,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     // address is recomputed in the load segment that issues it (~25 vector instructions; those segments have slack).
     int pt_b = 0, pt_y0 = 0, pt_x0 = 0;                 // 2-D: image and origin (incl. halo) of the tile being prefetched
     int pt_j0 = 0;                                      // flat: NHW pixel of patch row 0 (M = B*H*W < 2^31)
+    auto mt_of = [&](int item) -> int { return p.n_major ? item % p.m_tiles : item / p.n_tiles; };
+    auto nt_of = [&](int item) -> int { return p.n_major ? item / p.m_tiles : item % p.n_tiles; };
     auto patch_tile = [&](int item) {                   // (wave-uniform scalars; once per prefetched chunk)
-        const int mt = item / p.n_tiles;
+        const int mt = mt_of(item);
         if (TW) {
             const int b = mt / p.tiles_per_img, tt = mt - b * p.tiles_per_img;
             const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     // byte offset into p.w of the weight slice of (item, chunk c, tap 0); a tap adds Cin*ES  (32-bit scalars: a 64-bit pointer
     // that hipcc cannot prove wave-uniform lands in a VGPR pair -- and is spilled)
     auto weight_off = [&](int item, int c) -> unsigned {
-        return (unsigned)__builtin_amdgcn_readfirstlane((item % p.n_tiles) * BN * p.Ktot * ES + c * 128);
+        return (unsigned)__builtin_amdgcn_readfirstlane(nt_of(item) * BN * p.Ktot * ES + c * 128);
     };
     // piece k (0..3) of the slice at byte offset `off` -> my group's half of weight slot `slot`
     auto weight_piece = [&](int k, unsigned off, int slot) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
             glds16(p.w + off, w + k * wstep, __builtin_amdgcn_readfirstlane(smem_lds + OFF_W + slot * WBYTES + grp * (WBYTES / 2) + (cw + 4 * k) * 1024));
     };
     auto load_bias = [&](int item) {                    // wave 0: the item's 256 biases = one 1-KiB piece
-        glds16((const char *)(p.bias + (item % p.n_tiles) * BN), (unsigned)opaque_lane() * 16u, smem_lds + OFF_B);
+        glds16((const char *)(p.bias + nt_of(item) * BN), (unsigned)opaque_lane() * 16u, smem_lds + OFF_B);
     };
 
     // =========================== compute state ===========================
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     long long tile_pix0 = 0;                            // 2-D: global pixel of the tile's (0,0); flat: mt*256
     int tile_row0 = 0, tile_x0 = 0;                     // 2-D: b*H + y and x of the tile's (0,0)
     auto setup_item = [&](int item) {
-        const int mt = item / p.n_tiles;
-        n0 = (item - mt * p.n_tiles) * BN;
+        const int mt = mt_of(item);
+        n0 = nt_of(item) * BN;
         if (mt == cur_mt) return;
         cur_mt = mt;
         if (TW) {
@@ -762,6 +765,14 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
     }
     p.n_tiles = a.Npad / 256;
     p.items = p.m_tiles * p.n_tiles;
+    {
+        // With two or more cout tiles an XCD whose items are (pixel tile, cout tile) pairs keeps the WHOLE weight matrix live (4.7 MB at
+        // 512 x 512, more than its 4-MB L2, and under the chained split its workgroups are at different channel chunks at the same
+        // time): cout-tile-major numbering gives an XCD one cout tile's weights (2.4 MB) at the price of reading every patch on two XCDs.
+        static int nm = -1;
+        if (nm < 0) { const char *e = getenv("TDRN_PP_NMAJOR"); nm = e ? atoi(e) : 1; }
+        p.n_major = (nm && p.n_tiles > 1) ? 1 : 0;
+    }
     if (p.items <= 0) return TDRN_OK;
     // below ~3/4 of a full grid the loader/consumer kernel's smaller (128- / 64-cout) items fill more CUs: measured 2x faster
     // at 50-100 items, equal at 200 (the two kernels produce the same bits, so the choice may depend on the batch)

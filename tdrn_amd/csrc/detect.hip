@@ -848,4 +848,99 @@ int launch_nms_classes(const float *boxes, const float *scores, int n, int C, in
     return hip_status(hipGetLastError());
 }
 
+// ---- DetectOTA's association arithmetic (layers/functions/detection_ota.py:86-99, layers/box_utils.py:295-367) ------------
+// ROI feature: the box's cell range [x0,x1) x [y0,y1) of the (C,H,W) feature map resampled to S x S with
+// F.upsample(mode='bilinear', align_corners=True)'s arithmetic (source index = dst * (in - 1) / (out - 1) in fp32, the
+// upper neighbour clamped to the crop, weights 1 - l and l), flattened as (C, S, S).  One thread per output element.
+__global__ __launch_bounds__(256) void roi_resample_kernel(const float *__restrict__ feat, int C, int H, int W, const int *__restrict__ cells,
+                                                           int n, int S, float *__restrict__ out)
+{
+    const int per = C * S * S;
+    const long long total = (long long)n * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / per), r = (int)(i - (long long)b * per);
+        const int c = r / (S * S), q = r - c * S * S, oy = q / S, ox = q - oy * S;
+        const int x0 = cells[4 * b], y0 = cells[4 * b + 1], x1 = cells[4 * b + 2], y1 = cells[4 * b + 3];
+        const int ih = y1 - y0, iw = x1 - x0;
+        float v = 0.f;
+        if (ih > 0 && iw > 0) {
+            const float sh = S > 1 ? (float)(ih - 1) / (float)(S - 1) : 0.f, sw = S > 1 ? (float)(iw - 1) / (float)(S - 1) : 0.f;
+            const float hr = sh * oy, wr = sw * ox;
+            const int h1 = (int)hr, w1 = (int)wr;
+            const int hp = h1 < ih - 1 ? 1 : 0, wp = w1 < iw - 1 ? 1 : 0;
+            const float hl1 = hr - h1, hl0 = 1.f - hl1, wl1 = wr - w1, wl0 = 1.f - wl1;
+            const float *f = feat + ((size_t)c * H + (y0 + h1)) * W + (x0 + w1);
+            v = hl0 * (wl0 * f[0] + wl1 * f[wp]) + hl1 * (wl0 * f[(size_t)hp * W] + wl1 * f[(size_t)hp * W + wp]);
+        }
+        out[i] = v;
+    }
+}
+
+int launch_roi_resample(const float *feat, int C, int H, int W, const int32_t *cells, int n, int S, float *out, hipStream_t s)
+{
+    if (!feat || !cells || !out || C < 1 || H < 1 || W < 1 || S < 1) return TDRN_E_ARG;
+    if (n <= 0) return TDRN_OK;
+    const long long total = (long long)n * C * S * S;
+    dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+    hipLaunchKernelGGL(roi_resample_kernel, grid, dim3(256), 0, s, feat, C, H, W, cells, n, S, out);
+    return hip_status(hipGetLastError());
+}
+
+// similarity of detection i to tubelet j = exp(IoU(box_i, head_j)) * mean over the tubelet's stored rows r of cos(roi_i, row_r)
+// (box_utils.IoU: normalised boxes, no "+1"; box_utils.cos_similarity), then the row maximum and its (first) argument
+// (detection_ota.py:99).  rows (R, 5 + F): [score, box, feature] of every tubelet back to back, newest row (the head) first;
+// row_off (m + 1).  One workgroup per detection.
+__global__ __launch_bounds__(256) void ota_similarity_kernel(const float *__restrict__ boxes, const float *__restrict__ roi, int F,
+                                                             const float *__restrict__ rows, const int *__restrict__ row_off, int m,
+                                                             float *__restrict__ best, int *__restrict__ arg)
+{
+    __shared__ float red[3][4];
+    const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *ri = roi + (size_t)i * F;
+    auto block_sum = [&](float a, float b, float &sa, float &sb) {
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        __syncthreads();
+        if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+        __syncthreads();
+        sa = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        sb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    };
+    float rn2 = 0.f, dummy = 0.f;
+    for (int k = t; k < F; k += 256) rn2 = fmaf(ri[k], ri[k], rn2);
+    block_sum(rn2, 0.f, rn2, dummy);
+    const float rn = sqrtf(rn2);
+    const float bx0 = boxes[4 * i], by0 = boxes[4 * i + 1], bx1 = boxes[4 * i + 2], by1 = boxes[4 * i + 3];
+    const float area = (bx1 - bx0) * (by1 - by0);
+    float bestv = -INFINITY;
+    int besti = 0;
+    for (int j = 0; j < m; ++j) {
+        const int r0 = row_off[j], r1 = row_off[j + 1];
+        float cs = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float *tf = rows + (size_t)r * (5 + F) + 5;
+            float d = 0.f, n2 = 0.f;
+            for (int k = t; k < F; k += 256) { const float v = tf[k]; d = fmaf(ri[k], v, d); n2 = fmaf(v, v, n2); }
+            block_sum(d, n2, d, n2);
+            cs += d / (rn * sqrtf(n2));
+        }
+        cs /= (float)(r1 - r0);
+        const float *h = rows + (size_t)r0 * (5 + F);              // head row: [score, x1, y1, x2, y2]
+        const float ix0 = fmaxf(bx0, h[1]), iy0 = fmaxf(by0, h[2]), ix1 = fminf(bx1, h[3]), iy1 = fminf(by1, h[4]);
+        const float inter = fmaxf(ix1 - ix0, 0.f) * fmaxf(iy1 - iy0, 0.f);
+        const float iou = inter / ((area - inter) + (h[3] - h[1]) * (h[4] - h[2]));
+        const float sim = expf(iou) * cs;
+        if (sim > bestv) { bestv = sim; besti = j; }
+    }
+    if (t == 0) { best[i] = bestv; arg[i] = besti; }
+}
+
+int launch_ota_similarity(const float *boxes, const float *roi, int n, int F, const float *rows, const int32_t *row_off, int m, float *best,
+                          int32_t *arg, hipStream_t s)
+{
+    if (!boxes || !roi || !rows || !row_off || !best || !arg || F < 1 || m < 1) return TDRN_E_ARG;
+    if (n <= 0) return TDRN_OK;
+    hipLaunchKernelGGL(ota_similarity_kernel, dim3((unsigned)n), dim3(256), 0, s, boxes, roi, F, rows, row_off, m, best, arg);
+    return hip_status(hipGetLastError());
+}
+
 }  // namespace tdrn

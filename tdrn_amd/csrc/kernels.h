@@ -163,6 +163,10 @@ int launch_detect(const float *loc, const float *conf, const float *priors, cons
                   hipStream_t s);
 size_t nms_workspace_bytes(int n);
 size_t nms_classes_workspace_bytes(int n, int C);
+// DetectOTA's association arithmetic (detect.hip): ROI features of kept boxes, similarity of detections to tubelets
+int launch_roi_resample(const float *feat, int C, int H, int W, const int32_t *cells, int n, int S, float *out, hipStream_t s);
+int launch_ota_similarity(const float *boxes, const float *roi, int n, int F, const float *rows, const int32_t *row_off, int m, float *best,
+                          int32_t *arg, hipStream_t s);
 int launch_nms_classes(const float *boxes, const float *scores, int n, int C, int first_class, float overlap, float min_score, int top_k,
                        int32_t *keep_out, int32_t *num_out, void *ws, size_t ws_bytes, hipStream_t s);
 int launch_nms(const float *dets, int n, double thresh, int strict_gt, int presorted,

@@ -5,7 +5,9 @@ Split like the reference's own cost profile: what touches every prior runs on th
 two-stage decode (tdrn_decode / tdrn_center_size) and the NMS of ALL classes in ONE launch with box_utils.nms's rule
 (tdrn_nms_topk_classes: normalised boxes, no "+1", top_k best candidates only, IoU <= overlap survives) -- while the tubelet
 bookkeeping on the handful of survivors (python dictionaries in the reference too) stays host-driven, with its small
-tensors on the GPU.  Host round trips per frame: ONE for the counts, kept indices, scores and boxes of all classes; with
+tensors on the GPU; the association ARITHMETIC is the library's too: tdrn_roi_resample (the 7x7 bilinear ROI features of all kept
+boxes of a frame in one launch) and tdrn_ota_similarity (exp(IoU) x mean cosine against every tubelet, row maximum and argument:
+one launch per class that has tubelets) -- torch is left with moving bytes (cat / stack / slicing).  Host round trips per frame: ONE for the counts, kept indices, scores and boxes of all classes; with
 tub > 0 ONE more for the similarity decisions of all classes (the reference syncs per class and per box).
 Tie rule: equal scores keep the LOWER prior index first (tdrn_nms_topk); box_utils.nms walks an ascending torch.sort from the
 end, whose tie order is unspecified -- the fixture (tests/golden/detect_ota.npz) is tie-free at the top_k cut.
@@ -15,7 +17,6 @@ newest first, and hold = frames the tubelet survives without a match (loss_hold_
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from ... import _lib
 from ..box_utils import center_size, decode
@@ -79,36 +80,34 @@ class Detect(object):
             del self.tubelets[cl][ide]
         self.ides[cl] = [float(k) for k in self.tubelets[cl].keys()]
 
-    # ---- association pieces (layers/box_utils.py:295-367) --------------------------------------------------------
-    def _roi_feature(self, feature, box):
-        """:86-93: the box's cell range on the feature map, resampled to 7x7 (bilinear, align_corners) and flattened."""
-        Hf, Wf = feature.size(-2), feature.size(-1)
-        b = box.tolist()
-        x0 = int(np.clip(np.floor(b[0] * Wf), 0, Wf)); y0 = int(np.clip(np.floor(b[1] * Hf), 0, Hf))
-        x1 = int(np.clip(np.ceil(b[2] * Wf), 0, Wf)); y1 = int(np.clip(np.ceil(b[3] * Hf), 0, Hf))
-        s = self.tub_feature_size
-        return F.interpolate(feature[:, :, y0:y1, x0:x1], (s, s), mode='bilinear', align_corners=True).reshape(-1, s * s * feature.size(1))
+    # ---- association pieces (detection_ota.py:86-99, layers/box_utils.py:295-367) on the device ------------------------
+    def _roi_features(self, feature, cells_h):
+        """:86-93 for all kept boxes of a frame: cells_h (n,4) host int32 [x0,y0,x1,y1] -> (n, Cf*7*7) fp32 on the device."""
+        lib = _lib.lib()
+        dev = feature.device
+        n = cells_h.shape[0]
+        fm = feature.reshape(feature.size(-3), feature.size(-2), feature.size(-1)).contiguous().float()
+        s7 = self.tub_feature_size
+        out = torch.empty((n, fm.size(0) * s7 * s7), dtype=torch.float32, device=dev)
+        cells = torch.from_numpy(np.ascontiguousarray(cells_h, np.int32)).to(dev)
+        _lib.check(lib.tdrn_roi_resample(_lib.ptr(fm), fm.size(0), fm.size(1), fm.size(2), _lib.ptr(cells), n, s7, _lib.ptr(out),
+                                         _lib.current_stream(dev)), "tdrn_roi_resample")
+        return out
 
-    @staticmethod
-    def _iou_to_tubelets(boxes, heads):
-        """box_utils.IoU: boxes (n,4) against the newest [score, box] row of every tubelet (m,5) -> (n,m); no "+1"."""
-        x1 = torch.maximum(boxes[:, None, 0], heads[None, :, 1]); y1 = torch.maximum(boxes[:, None, 1], heads[None, :, 2])
-        x2 = torch.minimum(boxes[:, None, 2], heads[None, :, 3]); y2 = torch.minimum(boxes[:, None, 3], heads[None, :, 4])
-        inter = (x2 - x1).clamp(min=0.0) * (y2 - y1).clamp(min=0.0)
-        area = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))[:, None]
-        area_t = ((heads[:, 3] - heads[:, 1]) * (heads[:, 4] - heads[:, 2]))[None, :]
-        return inter / ((area - inter) + area_t)
-
-    @staticmethod
-    def _cos_to_tubelets(feats, tubelets):
-        """box_utils.cos_similarity: mean over a tubelet's stored rows of the cosine between the roi and that row."""
-        roi = torch.cat(feats, 0)                                             # (n, F)
-        rn = roi.norm(2, dim=1)
-        cols = []
-        for _, (tube, _hold) in tubelets.items():
-            tf = tube[:, 5:]                                                  # (t, F)
-            cols.append(((roi @ tf.t()) / (rn[:, None] * tf.norm(2, dim=1)[None, :])).mean(dim=1))
-        return torch.stack(cols, 1)
+    def _similarity(self, nms_box, roi, tubes):
+        """:95-99: (max over tubelets of exp(IoU) * mean cosine, its index) per detection, on the device."""
+        lib = _lib.lib()
+        dev = roi.device
+        rows = torch.cat([t[0] for t in tubes.values()], 0).contiguous()             # (R, 5 + F), a tubelet's newest row first
+        off = np.zeros(len(tubes) + 1, np.int32)
+        off[1:] = np.cumsum([t[0].size(0) for t in tubes.values()])
+        row_off = torch.from_numpy(off).to(dev)
+        n = roi.size(0)
+        best = torch.empty(n, dtype=torch.float32, device=dev)
+        arg = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(lib.tdrn_ota_similarity(_lib.ptr(nms_box), _lib.ptr(roi), n, roi.size(1), _lib.ptr(rows), _lib.ptr(row_off), len(tubes),
+                                           _lib.ptr(best), _lib.ptr(arg), _lib.current_stream(dev)), "tdrn_ota_similarity")
+        return best, arg
 
     def _nms_all_classes(self, boxes, conf_i):
         """box_utils.nms for every class of one frame: ONE launch, ONE host read.  boxes (P,4), conf_i (P,C) on the device ->
@@ -181,21 +180,27 @@ class Detect(object):
             # ---- tub > 0: roi features and similarities of every class on the device, decisions read back ONCE ----------
             Hf, Wf = feature.size(-2), feature.size(-1)
             feats, sims = {}, {}
+            cells, first = [], {}
+            for cl in range(1, C):
+                n = int(counts[cl])
+                if n:
+                    first[cl] = len(cells)
+                    cells += [self._roi_cells(b, Hf, Wf) for b in bx_h[cl, :n]]
+            if cells:
+                cells = np.asarray(cells, np.int32)
+                if ((cells[:, 2] <= cells[:, 0]) | (cells[:, 3] <= cells[:, 1])).any():
+                    raise RuntimeError("a kept box covers no cell of the feature map (the reference's F.upsample raises here too)")
+                roi_all = self._roi_features(feature, cells)                   # one launch for the frame
             for cl in range(1, C):
                 n = int(counts[cl])
                 if n == 0:
                     continue
-                fl = []
-                for b in bx_h[cl, :n]:
-                    x0, y0, x1, y1 = self._roi_cells(b, Hf, Wf)
-                    fl.append(F.interpolate(feature[:, :, y0:y1, x0:x1], (s7, s7), mode='bilinear', align_corners=True).reshape(-1, s7 * s7 * feature.size(1)))
-                feats[cl] = fl
+                roi = roi_all[first[cl]:first[cl] + n]
+                feats[cl] = roi
                 tubes = self.tubelets[cl]
                 if tubes:
-                    nms_box = boxes[ids[cl, :n]]
-                    heads = torch.stack([t[0][0, :5] for t in tubes.values()], 0)
-                    sim = torch.exp(self._iou_to_tubelets(nms_box, heads)) * self._cos_to_tubelets(fl, tubes)
-                    sims[cl] = sim.max(dim=1)
+                    nms_box = boxes[ids[cl, :n]].contiguous()
+                    sims[cl] = self._similarity(nms_box, roi, tubes)
             if sims:
                 order = sorted(sims)
                 flat = torch.cat([torch.cat((sims[cl][0], sims[cl][1].float())) for cl in order]).cpu().numpy()   # the second host read
@@ -233,10 +238,10 @@ class Detect(object):
                 out_h[i, cl, :n, 1:5] = bx_h[cl, :n]
                 out_h[i, cl, :n, 5] = identity
                 rows = torch.from_numpy(out_h[i, cl, :n, :5].copy()).to(dev)     # [score, box] of the survivors (H2D, no sync)
-                for r, (fea, ide) in enumerate(zip(feats[cl], identity.tolist())):
+                for r, ide in enumerate(identity.tolist()):
                     if ide < 0:
                         continue
-                    info = torch.cat((rows[r:r + 1], fea), dim=1)               # [score, box, roi feature]
+                    info = torch.cat((rows[r:r + 1], feats[cl][r:r + 1]), dim=1)   # [score, box, roi feature]
                     key = int(ide)
                     if key in tubes:
                         info = torch.cat((info, tubes[key][0]), 0)[:self.tub]

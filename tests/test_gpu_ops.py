@@ -356,6 +356,57 @@ def test_detect_ota_matches_reference_sequence(golden_dir, tub):
         DetectOTA(21, 0, 200, 0.01, 0.0)
 
 
+def test_roi_resample_and_ota_similarity_match_torch():
+    """DetectOTA's association arithmetic as the library's own kernels (tdrn_roi_resample, tdrn_ota_similarity) against the torch
+    ops the reference uses for it (layers/functions/detection_ota.py:86-99: F.upsample(bilinear, align_corners=True) of the box's
+    cell range; box_utils.IoU and cos_similarity, layers/box_utils.py:295-367), computed here with plain PyTorch on the CPU."""
+    import torch.nn.functional as F
+    lib = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(5))
+    Cf, Hf, Wf, S = 24, 20, 20, 7
+    feat = torch.from_numpy(rng.standard_normal((1, Cf, Hf, Wf)).astype(np.float32))
+    cells = np.array([[0, 0, 20, 20], [3, 4, 4, 5], [2, 7, 9, 8], [5, 1, 6, 19], [10, 10, 17, 13], [19, 19, 20, 20], [0, 12, 13, 20]], np.int32)
+    n = cells.shape[0]
+    out = torch.empty((n, Cf * S * S), dtype=torch.float32, device=DEV)
+    fd, cd = feat[0].contiguous().to(DEV), torch.from_numpy(cells).to(DEV)
+    _lib.check(lib.tdrn_roi_resample(_lib.ptr(fd), Cf, Hf, Wf, _lib.ptr(cd), n, S, _lib.ptr(out), _lib.current_stream(DEV)), "roi")
+    want = torch.cat([F.interpolate(feat[:, :, y0:y1, x0:x1], (S, S), mode="bilinear", align_corners=True).reshape(1, -1)
+                      for x0, y0, x1, y1 in cells.tolist()], 0)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+    # similarity: 7 detections against 5 tubelets of 1..4 stored rows
+    Fdim = Cf * S * S
+    xy = rng.uniform(0, 0.6, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + rng.uniform(0.1, 0.4, (n, 2)).astype(np.float32)], 1)
+    lens = [1, 4, 2, 3, 1]
+    tubes = []
+    for L in lens:
+        t = rng.standard_normal((L, 5 + Fdim)).astype(np.float32)
+        txy = rng.uniform(0, 0.6, (L, 2)).astype(np.float32)
+        t[:, 1:3] = txy
+        t[:, 3:5] = txy + rng.uniform(0.1, 0.4, (L, 2)).astype(np.float32)
+        tubes.append(torch.from_numpy(t))
+    tubes[2][:, 5:] = want[3:4] * 0.5 + 0.01 * tubes[2][:, 5:]                 # (one tubelet that resembles detection 3)
+    rows = torch.cat(tubes, 0).to(DEV)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(DEV)
+    best = torch.empty(n, dtype=torch.float32, device=DEV)
+    arg = torch.empty(n, dtype=torch.int32, device=DEV)
+    bd = torch.from_numpy(boxes).to(DEV)
+    _lib.check(lib.tdrn_ota_similarity(_lib.ptr(bd), _lib.ptr(out), n, Fdim, _lib.ptr(rows), _lib.ptr(off), len(lens), _lib.ptr(best),
+                                       _lib.ptr(arg), _lib.current_stream(DEV)), "sim")
+    b = torch.from_numpy(boxes)
+    heads = torch.stack([t[0, :5] for t in tubes], 0)
+    x1 = torch.maximum(b[:, None, 0], heads[None, :, 1]); y1 = torch.maximum(b[:, None, 1], heads[None, :, 2])
+    x2 = torch.minimum(b[:, None, 2], heads[None, :, 3]); y2 = torch.minimum(b[:, None, 3], heads[None, :, 4])
+    inter = (x2 - x1).clamp(min=0.0) * (y2 - y1).clamp(min=0.0)
+    iou = inter / ((((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[:, None] - inter) + ((heads[:, 3] - heads[:, 1]) * (heads[:, 4] - heads[:, 2]))[None, :])
+    cos = torch.stack([((want @ t[:, 5:].t()) / (want.norm(2, dim=1)[:, None] * t[:, 5:].norm(2, dim=1)[None, :])).mean(dim=1) for t in tubes], 1)
+    sim = torch.exp(iou) * cos
+    wb, wa = sim.max(dim=1)
+    np.testing.assert_allclose(best.cpu().numpy(), wb.numpy(), rtol=2e-5, atol=2e-6)
+    assert np.array_equal(arg.cpu().numpy(), wa.numpy().astype(np.int32))
+    assert int(arg[3]) == 2
+
+
 def test_nms_topk_is_box_utils_nms():
     """tdrn_nms_topk against a numpy restatement of layers/box_utils.py:229-293 written in the test (no "+1", top_k
     prefilter, IoU <= overlap survives, fp32), incl. the candidate threshold and a degenerate (zero-area) pair."""
