@@ -136,6 +136,12 @@ def cpu_baseline(size, frames=2):
                       "conv + C Detect), %.1f s" % (frames, dt)}
 
 
+# Engines, captured graphs and the streamed pipeline are kept until the process ends: on ROCm 7.2 hipGraphLaunch crashed (SIGSEGV)
+# for a graph captured AFTER earlier graphs / engines of the process had been destroyed (seen with the fp32 plan after two such
+# destructions, in either order of the blocks below); nothing is freed, nothing crashes -- 288 GB of HBM holds three engines.
+KEEP_ALIVE = []
+
+
 def detection_agreement(size, dtypes, dev, frames=8):
     """What each precision's error does to the FINAL detections (layers/functions/detection.py:25-70): Detect (HIP) on the
     HIP net's outputs against the oracle's Detect on the fp32 oracle's outputs, over `frames` synthetic frames, boxes in
@@ -438,7 +444,7 @@ def main():
                       "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | caller's stream: one hipGraph per slot = tdrn_preprocess, net, Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL),
                       "note": "the resident figure (`value`) starts from fp32 frames already preprocessed in HBM; this one includes the preprocess kernel and both copies"}
-        del fs
+        KEEP_ALIVE.append(fs)
 
     # ---- the other precisions of the same workload, timed in this run (N = 1 only) -----------------------------------
     modes = None
@@ -461,7 +467,7 @@ def main():
                           "repetitions": 3, "forward_only_ms_per_step": round(forward_ms(e2), 4),
                           "roofline": {"kernel": c2["name"], "achieved": round(a2, 2), "peak": PEAK_TFLOPS[dtm], "unit": "TFLOP/s",
                                        "frac": round(a2 / PEAK_TFLOPS[dtm], 4)}}
-            del st2, e2
+            KEEP_ALIVE.extend((st2, e2))
         net.set_compute_dtype(args.dtype)
 
     if rank == 0:
