@@ -177,6 +177,51 @@ def test_16bit_drift_is_bounded(family, dtype):
     _check_drift(family, dtype, net, sd, synth.synth_frames(1, 320, seed=5))
 
 
+def test_16bit_error_scales_with_the_significand():
+    """Two checks of the 16-bit modes against something OUTSIDE this repo's own measurements (DRIFT_MEASURED is a regression
+    guard):
+    (1) analytic, first layer: conv1_1 computes sum(x*w') with x and the BN-folded w' rounded to the 16-bit type (relative error
+        <= u = 2^-8 bf16 / 2^-11 fp16 each), fp32 accumulation, one rounding of the output -- so every element must satisfy
+        |y16 - y32| <= (2u + u^2) S + u (|y32| + (2u + u^2) S) + 1e-6 S,   S = sum |x| |w'|  (ReLU is 1-Lipschitz);
+    (2) end to end: the error of a whole net is the accumulated input rounding of its layers, so fp16 (11-bit significand)
+        must be at least 5x closer to the fp32 oracle than bf16 (8 bits; ideal ratio 8) on every output of every family."""
+    import torch.nn.functional as F
+    x = synth.synth_frames(1, 320, seed=5)
+    # (1)
+    for dtype, u in (("bf16", 2.0 ** -8), ("fp16", 2.0 ** -11)):
+        net, sd = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+        net.set_plan_flags(_lib.PLAN_NO_FUSE_FIRST)             # (conv1_1's output is a tensor of its own in this plan)
+        net.set_compute_dtype(dtype)
+        net(torch.from_numpy(x).to(DEV))
+        eng = net._engine
+        idx = [i for i, (lab, c, h, w) in enumerate(eng.tensor_infos()) if lab == "backbone.0"][0]
+        got = eng.read_tensor(idx, 1).cpu().double()
+        w = torch.from_numpy(sd["backbone.0.weight"]).double()
+        sc = torch.from_numpy(sd["backbone.1.weight"]).double() / torch.sqrt(torch.from_numpy(sd["backbone.1.running_var"]).double() + 1e-5)
+        wf = w * sc[:, None, None, None]
+        bf = (torch.from_numpy(sd["backbone.0.bias"]).double() - torch.from_numpy(sd["backbone.1.running_mean"]).double()) * sc \
+            + torch.from_numpy(sd["backbone.1.bias"]).double()
+        xt = torch.from_numpy(x).double()
+        y = F.conv2d(xt, wf, bf, padding=1)
+        S = F.conv2d(xt.abs(), wf.abs(), None, padding=1)
+        e1 = (2 * u + u * u) * S
+        bound = e1 + u * (y.abs() + e1) + 1e-6 * S
+        err = (got - y.clamp(min=0)).abs()
+        assert bool((err <= bound).all()), (dtype, float((err - bound).max()))
+        assert float(err.mean()) > 0.02 * float(bound.mean())        # (the bound is not vacuous: within 50x of the observed error)
+    # (2)
+    for family in sorted(FAMILIES):
+        errs = {}
+        for dtype in ("bf16", "fp16"):
+            net, sd = _build(family, FAMILIES[family][0])
+            net.set_compute_dtype(dtype)
+            ref = _split_outputs(FAMILIES[family][1](sd, x, {}))
+            got = _split_outputs(net(torch.from_numpy(x).to(DEV)))
+            errs[dtype] = [float((g.cpu() - r.reshape(g.shape)).abs().mean()) for g, r in zip(got, ref) if g is not None]
+        for eb, eh in zip(errs["bf16"], errs["fp16"]):
+            assert eh * 5.0 <= eb, (family, errs)
+
+
 def test_batch32_rows_equal_single_frame_runs():
     """Full BASELINE batch (32 frames, bf16): every frame's outputs are bit-identical to running it
     alone -- tile boundaries and batch position must not leak into the arithmetic."""
