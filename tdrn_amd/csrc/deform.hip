@@ -410,6 +410,7 @@ struct SampleParams {
     SampleBranchP br[2];
     int n_branches, n_taps;
     int M, H, W, ycs, Cout, split;
+    int tap_major;                 // y is [tap][B*H*W][80] instead
     float *out0, *out1;
     long long o0_bs, o0_ps, o1_bs, o1_ps;
 };
@@ -464,8 +465,8 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
             const int c0 = min(max(w_in + w_low, 0), p.W - 1), c1 = min(max(w_in + w_high, 0), p.W - 1);
             q1 = r0 * p.W + c0; q2 = r0 * p.W + c1; q3 = r1 * p.W + c0; q4 = r1 * p.W + c1;
         }
-        const unsigned colb = (unsigned)((B.col0 + tl) * kSampleCols * 2);
-        const unsigned rowb = (unsigned)(p.ycs * 2);
+        const unsigned colb = p.tap_major ? (unsigned)(B.col0 + tl) * (unsigned)p.M * (unsigned)(kSampleCols * 2) : (unsigned)(deform_y_col(B.col0 + tl) * 2);
+        const unsigned rowb = p.tap_major ? (unsigned)(kSampleCols * 2) : (unsigned)(p.ycs * 2);
         const unsigned img = (unsigned)(b * HW);
         s_off[wave][4 * lane + 0] = (img + q1) * rowb + colb; s_w[wave][4 * lane + 0] = w1;
         s_off[wave][4 * lane + 1] = (img + q2) * rowb + colb; s_w[wave][4 * lane + 1] = w2;
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
 struct YGemmParams {
     const char *x;     // [M][256] DT
     const char *w;     // [N][256] DT
-    char *y;           // [M][ycs] DT
-    int M, N, ycs, parts, tiles_per_part;
+    char *y;           // [M][ycs] DT, or tap-major [taps][M][80] (taps > 0): the layout the sampling launch gathers from
+    int M, N, ycs, parts, tiles_per_part, taps;
 };
 
 template <typename DT>
@@ -604,11 +605,27 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
         __builtin_amdgcn_s_waitcnt(0xC07F);              // my LDS reads of tile t have returned, my staging writes are done ...
         __builtin_amdgcn_s_barrier();                    // ... and everybody's: tile t's buffer may be refilled, the image is whole
         asm volatile("" ::: "memory");
+        if (p.taps > 0) {
+            // tap-major Y: [tap][pixel][80 columns].  A tap's 160-byte rows of consecutive pixels are contiguous, so the four bilinear
+            // corners of the sampling launch are two runs of 320 bytes and neighbouring output pixels share their cache lines.
+            // A slice holds three whole taps (deform_y_col); a wave stores one (tap, 6-pixel group) per trip: lane = 10 * pixel +
+            // chunk -> 960 contiguous bytes.
+            const int px = lane / 10, k = lane - 10 * px;
+            for (int it = wave; it < 18; it += 8) {                  // three taps per slice (deform_y_col) x six 6-pixel groups
+                const int sgi = it / 6, pg = it - sgi * 6;
+                const int tap = cg * 3 + sgi;
+                const int row = pg * 6 + px;
+                const long long m = (long long)(t0 + t) * TP + row;
+                if (lane < 60 && row < TP && tap < p.taps && m < p.M)
+                    *(u32x4 *)(p.y + ((size_t)tap * p.M + (size_t)m) * 160 + k * 16) = *(const u32x4 *)(sst + row * SROW + (sgi * 10 + k) * 16);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int row = (threadIdx.x >> 5) + 16 * q, ch = threadIdx.x & 31;      // 32 lanes = one pixel row of 512 B
-            const long long m = (long long)(t0 + t) * TP + row;
-            if (m < p.M) *(u32x4 *)(p.y + ((size_t)m * p.ycs + cg * 256) * 2 + ch * 16) = *(const u32x4 *)(sst + row * SROW + ch * 16);
+            for (int q = 0; q < 2; ++q) {
+                const int row = (threadIdx.x >> 5) + 16 * q, ch = threadIdx.x & 31;      // 32 lanes = one pixel row of 512 B
+                const long long m = (long long)(t0 + t) * TP + row;
+                if (m < p.M) *(u32x4 *)(p.y + ((size_t)m * p.ycs + cg * 256) * 2 + ch * 16) = *(const u32x4 *)(sst + row * SROW + ch * 16);
+            }
         }
         // (the next tile's staging writes come behind the barrier at the top of the next iteration: no wave can still be
         // reading this image then)
@@ -617,12 +634,13 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
 
 int ygemm_supported(int Cin, int ycols, int dtype) { return dtype != TDRN_F32 && Cin == 256 && ycols % 256 == 0; }
 
-int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s)
+int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s, int taps)
 {
     if (!ygemm_supported(256, N, dtype) || M <= 0 || M >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
     YGemmParams p;
     p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
-    p.M = (int)M; p.N = N; p.ycs = ycs;
+    p.M = (int)M; p.N = N; p.ycs = ycs; p.taps = taps;
+    if (taps > 0 && (deform_sample_cols(taps) > N || (long long)taps * M * 160 >= (1ll << 32))) return TDRN_E_UNSUPPORTED;
     const int tiles = (int)((M + 31) / 32), cgs = N / 256;
     // ~4 workgroups per CU in flight over the whole launch; a partition is at least 8 tiles (the weight prologue is 8 KiB per wave)
     int parts = (1024 + cgs - 1) / cgs;
@@ -648,10 +666,10 @@ int deform_sample_supported(const DeformArgs &a)
     }
     return taps <= 34 ? taps : 0;
 }
-int deform_sample_cols(int taps) { return (int)align_up((size_t)taps * kSampleCols, 256); }
+int deform_sample_cols(int taps) { return ((taps + 2) / 3) * 256; }
 
 // y[i]: the level's Y tensor ([B*H*W][ycs[i]], net dtype), computed by the caller's 1x1 GEMM with the branches' taps in order
-int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s)
+int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s, int tap_major)
 {
     if (!args || n < 1 || n > 4) return TDRN_E_ARG;
     SampleMulti mp;
@@ -672,7 +690,7 @@ int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, con
             col0 += b.kh * b.kw;
         }
         if (a.n_branches == 1) p.br[1] = p.br[0];
-        p.M = a.B * a.H * a.W; p.H = a.H; p.W = a.W; p.ycs = ycs[i]; p.Cout = a.Cout;
+        p.M = a.B * a.H * a.W; p.H = a.H; p.W = a.W; p.ycs = ycs[i]; p.Cout = a.Cout; p.tap_major = tap_major;
         p.split = a.split > a.Cout ? a.Cout : a.split;
         p.out0 = a.out0; p.out1 = a.out1;
         p.o0_bs = a.o0_bs; p.o0_ps = a.o0_ps; p.o1_bs = a.o1_bs; p.o1_ps = a.o1_ps;

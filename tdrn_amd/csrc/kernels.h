@@ -145,10 +145,13 @@ int deform_n_pad(int cout);
 // per-tap weight slabs ([taps][80 columns] per pixel, deform_sample_cols(taps) channels), this launch blends the corners
 int deform_sample_supported(const DeformArgs &a);      // 0 = no, else the number of taps of all branches
 int deform_sample_cols(int taps);
-int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s);
+// column of tap t's 80 outputs in the transform GEMM's output: three taps per 256-column slice (a slice of ygemm_k256 then holds
+// whole taps only; columns 240..255 of every slice are zero padding)
+constexpr int deform_y_col(int tap) { return (tap / 3) * 256 + (tap % 3) * 80; }
+int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s, int tap_major = 0);
 // Y = X[M][256] * Wt[N][256]^T in the net dtype, weights held in registers (deform.hip); N % 256 == 0
 int ygemm_supported(int Cin, int ycols, int dtype);
-int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s);
+int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s, int taps = 0);   // taps > 0: Y tap-major [taps][M][80]
 
 // ---------------------------------------------------------------------------------------------
 // Detect (detect.hip)

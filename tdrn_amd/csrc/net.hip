@@ -981,7 +981,7 @@ struct tdrn_net {
                 case OP_DEFORM: {
                     const Tensor &ti = tensors[o.in];
                     const int nc3 = 3 * cfg.num_classes;
-                    if (o.y_t >= 0) {        // rows (tap, column) of the 1x1 GEMM: tap-major over the branches, 80 columns per tap
+                    if (o.y_t >= 0) {        // rows (tap, column) of the 1x1 GEMM: tap-major over the branches, 80 columns per tap, three taps per 256-row slice (deform_y_col)
                         char *dt = host.data() + o.wt_off;
                         int tap0 = 0;
                         for (int br = 0; br < o.n_branches; ++br) {
@@ -994,7 +994,7 @@ struct tdrn_net {
                                     const std::vector<float> &src = co < 12 ? *wl : *wc;
                                     const int cs = co < 12 ? co : co - 12;
                                     for (int ci = 0; ci < ti.C; ++ci)
-                                        put_elem(dt, ((size_t)(tap0 + t) * 80 + co) * o.Cin + ci, src[((size_t)cs * ti.C + ci) * taps + t]);
+                                        put_elem(dt, ((size_t)deform_y_col(tap0 + t) + co) * o.Cin + ci, src[((size_t)cs * ti.C + ci) * taps + t]);
                                 }
                             tap0 += taps;
                         }
@@ -1144,6 +1144,13 @@ struct tdrn_net {
         };
         DeformArgs dargs[4];
         const void *ts_y[4] = {nullptr, nullptr, nullptr, nullptr};
+        // Y layout of the transform-then-sample heads: tap-major [tap][pixel][80] when every level's transform runs on ygemm_k256
+        // (which writes it), else the plain [pixel][columns] matrix of the generic GEMM
+        static int ts_tap_env = -1;
+        if (ts_tap_env < 0) { const char *e = getenv("TDRN_Y_TAP_MAJOR"); ts_tap_env = e ? atoi(e) : 1; }
+        int ts_tap_major = ts_tap_env ? 1 : 0;
+        for (const Op &d : ops)
+            if (d.kind == OP_DEFORM && d.y_t >= 0 && !ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) ts_tap_major = 0;
         int ts_cs[4] = {0, 0, 0, 0};
         int n_dargs = 0;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
@@ -1296,15 +1303,17 @@ struct tdrn_net {
                         g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0; g.phases = 1; g.dtype = cfg.dtype;
                         g.out = tptr(ws, o.y_t, B);
                         g.o_cs = o.y_cols; g.o_rs = (long long)ti.W * o.y_cols; g.o_bs = (long long)ti.H * ti.W * o.y_cols;
+                        int taps = 0;
+                        for (int k = 0; k < o.n_branches; ++k) taps += a.br[k].kh * a.br[k].kw;
                         if (ygemm_supported(o.Cin, o.y_cols, cfg.dtype))
-                            rc = launch_ygemm(g.in, g.w, g.out, (long long)B * ti.H * ti.W, o.y_cols, o.y_cols, cfg.dtype, s);
+                            rc = launch_ygemm(g.in, g.w, g.out, (long long)B * ti.H * ti.W, o.y_cols, o.y_cols, cfg.dtype, s, ts_tap_major ? taps : 0);
                         else
                             rc = launch_conv(g, s);
                         if (rc != TDRN_OK) break;
                         ts_y[n_dargs - 1] = g.out; ts_cs[n_dargs - 1] = o.y_cols;
                     }
                     if (!deform_batched && o.y_t >= 0) {   // ... then sample: all pyramid levels in one launch
-                        rc = launch_deform_sample_multi(dargs, ts_y, ts_cs, n_dargs, s);
+                        rc = launch_deform_sample_multi(dargs, ts_y, ts_cs, n_dargs, s, ts_tap_major);
                         n_dargs = 0;
                         break;
                     }
