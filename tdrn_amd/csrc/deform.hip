@@ -418,23 +418,29 @@ struct SampleMulti {
     SampleParams p[4];
     int block_start[5];
     int n;
+    int xcd_remap;
 };
 constexpr int kSampleCols = 80;    // Y columns per tap (75 used)
 
 template <typename DT>
 __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp)
 {
+    // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous run of the launch's blocks (= of output pixels,
+    // 4 per block), so that the Y rows shared by neighbouring pixels -- the x+1 / y+1 corners, the overlapping taps -- are fetched
+    // into ONE L2 instead of up to eight.
+    const int nblk = (int)gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = (int)blockIdx.x & 7;
+    const int blk = mp.xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     int prob = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
-        if (i < mp.n && (int)blockIdx.x >= mp.block_start[i]) prob = i;
+        if (i < mp.n && blk >= mp.block_start[i]) prob = i;
     const SampleParams &p = mp.p[prob];
     constexpr int MAXR = 34 * 4;                        // corner rows of one output pixel (9 + 25 taps)
     __shared__ unsigned s_off[4][MAXR + 8];             // per wave: byte offset of a corner's Y row (incl. the tap's columns)
     __shared__ float s_w[4][MAXR + 8];                  // ... and its bilinear weight (0: tap rejected)
     __shared__ float s_red[4][6][kSampleCols];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = ((int)blockIdx.x - mp.block_start[prob]) * 4 + wave;     // one wave = one output pixel (stride 1: Ho = H)
+    const int m = (blk - mp.block_start[prob]) * 4 + wave;                 // one wave = one output pixel (stride 1: Ho = H)
     if (m >= p.M) return;
     const int HW = p.H * p.W;
     const int b = m / HW, rem = m - b * HW, ho = rem / p.W, wo = rem - ho * p.W;
@@ -701,6 +707,11 @@ int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, con
     }
     if (mp.n == 0) return TDRN_OK;
     for (int i = mp.n; i < 4; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
+    {
+        static int remap = -1;
+        if (remap < 0) { const char *e = getenv("TDRN_SAMPLE_XCD"); remap = e ? atoi(e) : 1; }
+        mp.xcd_remap = remap;
+    }
     dim3 grid((unsigned)mp.block_start[mp.n]);
     if (args[0].dtype == TDRN_BF16) hipLaunchKernelGGL((deform_sample_kernel<bf16_t>), grid, dim3(256), 0, s, mp);
     else hipLaunchKernelGGL((deform_sample_kernel<f16_t>), grid, dim3(256), 0, s, mp);
