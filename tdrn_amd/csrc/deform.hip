@@ -574,14 +574,25 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
         }
     };
     stage(0, 0);
+    // 16-byte store instructions this wave issues per full tile (wave-uniform)
+    int nst_prev = 2;
+    if (p.taps > 0) {
+        nst_prev = 0;
+        for (int it = wave; it < 18; it += 8) nst_prev += (cg * 3 + it / 6) < p.taps ? 1 : 0;
+    }
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) {
             stage(t + 1, buf ^ 1);                       // (its last readers passed the barrier that ended tile t-1)
-            // tile t's two pieces must have landed; younger than them and free to stay in flight: the previous tile's TWO
-            // 16-byte stores (always issued: a tile inside the partition has a live row) and the two pieces just issued
-            if (t == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // tile t's two pieces must have landed; younger than them and free to stay in flight: the previous tile's 16-byte
+            // stores of THIS wave (nst_prev of them: two in the row-major layout -- always issued: a tile inside the partition has a
+            // live row --, 0..3 in the tap-major one, where the last slice holds fewer than three taps) and the two pieces just issued
+            switch (t == 0 ? 0 : nst_prev) {
+                case 0: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
