@@ -659,10 +659,20 @@ int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int 
     p.M = (int)M; p.N = N; p.ycs = ycs; p.taps = taps;
     if (taps > 0 && (deform_sample_cols(taps) > N || (long long)taps * M * 160 >= (1ll << 32))) return TDRN_E_UNSUPPORTED;
     const int tiles = (int)((M + 31) / 32), cgs = N / 256;
-    // ~4 workgroups per CU in flight over the whole launch; a partition is at least 8 tiles (the weight prologue is 8 KiB per wave)
-    int parts = (1024 + cgs - 1) / cgs;
-    if (parts > (tiles + 7) / 8) parts = (tiles + 7) / 8;
-    if (parts < 1) parts = 1;
+    // 512 workgroups are resident at a time (125 VGPRs: two 8-wave workgroups per CU).  The grid is cgs x parts workgroups of
+    // ceil(tiles / parts) tiles each; a partition is at least 8 tiles (the weight prologue is 8 KiB per wave).  The number of
+    // partitions is the candidate that minimises rounds x tiles per workgroup (measured with 256 / 512 / 768 / 1024 assumed slots:
+    // the 20x20 level 45.6 / 36.0 / 44.4 / 44.1 us, the 40x40 level 123-126 us whatever the partitioning -- it is not bound by
+    // rounds).
+    const int kSlots = 512, max_parts = (tiles + 7) / 8 > 1 ? (tiles + 7) / 8 : 1;
+    int parts = 1;
+    long long best = -1;
+    for (int r = 1; r <= 3; ++r) {
+        int c = kSlots * r / cgs;
+        c = c > max_parts ? max_parts : (c < 1 ? 1 : c);
+        const long long rounds = ((long long)cgs * c + kSlots - 1) / kSlots, cost = rounds * ((tiles + c - 1) / c);
+        if (best < 0 || cost < best) { best = cost; parts = c; }
+    }
     p.parts = parts;
     p.tiles_per_part = (tiles + parts - 1) / parts;
     dim3 grid((unsigned)cgs, (unsigned)parts);
