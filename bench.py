@@ -27,6 +27,16 @@ The JSON line also carries
   cpu_baseline : the CPU oracle (torch-CPU convs + C deformable conv + C Detect) on a bounded sample
                  of the same workload on this host's cores (rank 0, N=1 only)
 
+`--config N` selects another BASELINE.json configuration (default 2, the headline -- the driver's command is unchanged):
+  3  dualrefinedet_vggbn 512x512 fp16 batch 16 (same line shape, MFMA roofline)
+  4  dualrefinedet_mobilenet 320x320 batch 64 per GPU: HBM roofline (the MobileNet models are bandwidth-bound) --
+     algorithmic bytes of a step (layer-boundary activations once in / once out + the weights once) / the forward's time,
+     against 8 TB/s; the per-family table (`kernels`) carries each family's algorithmic bytes and time
+  5  TRN clips (evaluate_trn.py:438-467): 8 clips x 4 frames per step, interval 4: per clip 1 static forward (ssd4scale_vgg,
+     loc maps out) + 4 temporal forwards (ssd4scale_vgg deform=True, 8 deformable groups; offsets from the key frame) + 4
+     Detect calls; value = frames/s (clips/s beside it), MFMA roofline of the 3x3 conv family over both nets
+--size / --dtype / --batch override the preset.
+
 `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N ranks (fresh child processes, one per
 GPU, RCCL over 127.0.0.1) BEFORE anything in this process touches a GPU and relays rank 0's JSON line.
 """
@@ -42,6 +52,17 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md, dense
 GFLOP_PER_FRAME = {320: 77.466, 512: 198.314}                   # BASELINE.md section 2 (multihead)
+HBM_PEAK_GBS = 8000.0                                            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# BASELINE.json configs[1..4] (configs[0] is the reference's own CPU plumbing case)
+CONFIGS = {
+    2: dict(model="dualrefinedet_vggbn", size=320, dtype="bf16", batch=32),
+    3: dict(model="dualrefinedet_vggbn", size=512, dtype="fp16", batch=16),
+    4: dict(model="dualrefinedet_mobilenet", size=320, dtype="bf16", batch=64),
+    5: dict(model="trn_ssd4scale_vgg", size=320, dtype="bf16", batch=8),      # batch = clips of 4 frames
+}
+# algorithmic GFLOP per frame and layer-boundary activation elements per frame (M)
+MOBILENET_GFLOP, MOBILENET_ACT_MELEMS = 22.340, 55.2
+SSD4SCALE_VGG_GFLOP = 65.442
 
 
 def pmc_traffic(kernel, args, build):
@@ -234,14 +255,313 @@ def spawn_ranks(n):
     sys.exit(0)
 
 
+NUMA_PIN = None
+
+
+def pin_rank_to_numa_node():
+    """N > 1: every rank pins itself to the CPUs of its GPU's NUMA node BEFORE its first GPU call (tdrn_amd/dist.py, sysfs only):
+    the frame feeders of 8 ranks otherwise share whatever cores the launcher left them on."""
+    global NUMA_PIN
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("TDRN_NUMA_PIN", "1") != "0":
+        from tdrn_amd import dist as tdist
+        NUMA_PIN = tdist.pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")), world)
+
+
+def _timed(stepper, steps, reps, tdist, torch, dev):
+    out = []
+    for _ in range(reps):
+        tdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            stepper(k)
+        torch.cuda.synchronize()
+        tdist.barrier()
+        out.append(tdist.max_over_ranks(time.perf_counter() - t0, dev))
+    return out
+
+
+def _family_table(stats_prod, stats_solo, mult=1):
+    solo_ms = {s["name"]: s["ms"] for s in stats_solo}
+    return {s["name"]: {"ms": round(s["ms"] * mult, 4), "ms_single_stream": round(solo_ms.get(s["name"], 0.0) * mult, 4), "launches": s["launches"] * mult,
+                        "gflop": round(s["flops"] * mult / 1e9, 3), "gbyte": round(s["bytes"] * mult / 1e9, 4),
+                        "gbyte_per_s": round(s["bytes"] / 1e9 / (s["ms"] * 1e-3), 1) if s["ms"] > 0 else 0.0,
+                        "tflop_per_s": round(s["flops"] / 1e12 / (s["ms"] * 1e-3), 1) if s["ms"] > 0 else 0.0} for s in stats_prod}
+
+
+def main_other(args):
+    """BASELINE configs #4 (dualrefinedet_mobilenet 320, batch 64, HBM roofline) and #5 (TRN clips, MFMA roofline): the same
+    contract and line shape as the headline configuration."""
+    import numpy as np
+    import torch
+    from tdrn_amd import _lib
+    from tdrn_amd import dist as tdist
+    from tdrn_amd.data import mb_cfg
+    from tdrn_amd.engine import GraphedCall
+    from tdrn_amd.layers import Detect, PriorBox
+    from tdrn_amd.utils import synth
+
+    rank, local_rank, world = tdist.init()
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    build = _lib.lib().tdrn_version().decode()
+    S, B, NB = args.size, args.batch, max(1, args.batches)
+    es = 4 if args.dtype == "fp32" else 2
+    pri = PriorBox(mb_cfg["VOC_320" if S == 320 else "VOC_512_RefineDet"]).forward().to(dev)
+    scale = [500.0, 375.0, 500.0, 375.0]
+    trn = args.config == 5
+
+    def make(modname, a, kw, seed):
+        import importlib
+        net = importlib.import_module("tdrn_amd.model." + modname).build_net("test", *a, **kw)
+        net.set_compute_dtype(args.dtype)
+        sd = None
+        if rank == 0:
+            sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        t0 = time.perf_counter()
+        eng = net.adopt_broadcast_weights(src=0, device=dev) if world > 1 else net.engine(dev)
+        torch.cuda.synchronize()
+        return net, sd, eng, (time.perf_counter() - t0) * 1e3
+
+    if trn:
+        stat, sd_s, eng_s, bc1 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=False), 0)
+        temp, sd_t, eng_t, bc2 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=True), 1)
+        bcast_ms = bc1 + bc2
+        FPC = 4                                                  # frames per clip = the key-frame interval
+        det = [Detect(21, 0, 200, 0.01, 0.45) for _ in range(FPC)]
+        xb = [torch.from_numpy(synth.synth_frames(B * FPC, S, seed=100 + rank + 1000 * j)).to(dev).view(B, FPC, 3, S, S) for j in range(NB)]
+
+        def one_step(clips):
+            # evaluate_trn.py:438-467 over B clips at once: key frame -> static net (anchors + loc maps) -> temporal net
+            # (offsets from the loc maps); the following frames reuse the cached offsets; Detect per frame on the static anchors
+            s_loc, _, maps = stat(clips[:, 0].contiguous(), ret_loc=True)
+            outs, offs = [], None
+            for f in range(FPC):
+                xf = clips[:, f].contiguous()
+                if f == 0:
+                    loc, conf, offs = temp(xf, ref_loc=maps, ret_off=True)
+                else:
+                    loc, conf = temp(xf, offset_list=offs)
+                outs.append(conf if args.no_detect else det[f].forward(loc, conf, pri, arm_loc_data=s_loc, scale=scale))
+            return outs
+        frames_per_step = B * FPC
+        gflop_step = B * (SSD4SCALE_VGG_GFLOP + FPC * SSD4SCALE_VGG_GFLOP)     # (plain heads ~ deformable heads in FLOPs: same taps, same channels)
+        engines = [(eng_s, 1), (eng_t, FPC)]
+        name = "TRN ssd4scale_vgg static + temporal (deform, 8 groups)"
+    else:
+        net, sd, eng, bcast_ms = make("dualrefinedet_mobilenet", (S, 21), dict(def_groups=1, multihead=True), 0)
+        det = Detect(21, 0, 200, 0.01, 0.45)
+        xb = [torch.from_numpy(synth.synth_frames(B, S, seed=100 + rank + 1000 * j)).to(dev) for j in range(NB)]
+
+        def one_step(x):
+            r = eng.forward(x)
+            return r["conf"] if args.no_detect else det.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
+        frames_per_step = B
+        gflop_step = B * MOBILENET_GFLOP
+        engines = [(eng, 1)]
+        name = "dualrefinedet_mobilenet multihead"
+
+    if args.graph:
+        graphs = [GraphedCall(one_step, xb[j]) for j in range(NB)]
+        KEEP_ALIVE.append(graphs)
+        step = lambda k: graphs[k % NB](graphs[k % NB].inputs[0])
+    else:
+        step = lambda k: one_step(xb[k % NB])
+    for k in range(args.warmup):
+        step(k)
+    reps = sorted(_timed(step, args.steps, max(1, args.reps), tdist, torch, dev))
+    dt = reps[len(reps) // 2]
+    fps = world * frames_per_step * args.steps / dt
+
+    # forward-only time of a step (eager, no Detect), and the per-family accounting of one step
+    def fwd_only():
+        if trn:
+            clips = xb[0]
+            _, _, maps = stat(clips[:, 0].contiguous(), ret_loc=True)
+            offs = None
+            for f in range(FPC):
+                xf = clips[:, f].contiguous()
+                if f == 0:
+                    _, _, offs = temp(xf, ref_loc=maps, ret_off=True)
+                else:
+                    temp(xf, offset_list=offs)
+        else:
+            eng.forward(xb[0])
+    fwd_only()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        fwd_only()
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    def profiled(mode):
+        fam = {}
+        for e, mult in engines:
+            e.set_profile(mode)
+        fwd_only(); fwd_only()
+        torch.cuda.synchronize()
+        per_engine = []
+        for e, mult in engines:
+            st = e.kernel_stats()
+            per_engine.append((st, e.op_stats() if args.per_op else None, mult))
+            for srow in st:
+                f = fam.setdefault(srow["name"], dict(name=srow["name"], launches=0, flops=0.0, bytes=0.0, ms=0.0))
+                for kk in ("launches", "flops", "bytes", "ms"):
+                    f[kk] += srow[kk] * mult
+            e.set_profile(0)
+        return list(fam.values()), per_engine
+    solo, per_solo = profiled(1)
+    prod, per_prod = profiled(2)
+    if args.per_op and rank == 0:
+        for (st, ops, mult), (st2, ops2, _) in zip(per_solo, per_prod):
+            p2 = {o["name"]: o["ms"] for o in ops2}
+            print("%-44s %11s %11s %8s %9s %8s %9s   (x%d per step)" % ("launch", "alone us", "in step us", "GFLOP", "TFLOP/s", "GB", "GB/s", mult), file=sys.stderr)
+            for o in ops:
+                tf = o["flops"] / (o["ms"] * 1e-3) / 1e12 if o["ms"] > 0 else 0.0
+                gb = o["bytes"] / (o["ms"] * 1e-3) / 1e9 if o["ms"] > 0 else 0.0
+                print("%-44s %11.1f %11.1f %8.1f %9.1f %8.3f %9.0f" % (o["name"], o["ms"] * 1e3, p2.get(o["name"], 0.0) * 1e3, o["flops"] / 1e9, tf, o["bytes"] / 1e9, gb), file=sys.stderr)
+    kernels = _family_table(prod, solo)
+    dom = max(prod, key=lambda f: f["ms"])
+    dom_solo = next(f for f in solo if f["name"] == dom["name"])
+    if trn:
+        peak = PEAK_TFLOPS[args.dtype]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        ach_s = dom_solo["flops"] / (dom_solo["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "traffic_source": "no PMC pass committed for this workload", "launches_per_step": dom["launches"],
+                    "gflop_per_launch": round(dom["flops"] / 1e9 / dom["launches"], 2), "us_per_launch": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                    "mode": "production schedule (side lanes on)",
+                    "single_stream": {"achieved": round(ach_s, 2), "frac": round(ach_s / peak, 4), "us_per_launch": round(dom_solo["ms"] * 1e3 / dom_solo["launches"], 2)}}
+    else:
+        # HBM roofline of the whole forward (SURVEY 8d: the MobileNet models are bandwidth-bound, ~200 FLOP/B): algorithmic bytes =
+        # every layer-boundary activation once out and once in (BASELINE.md section 2: 55.2 M elements per frame at 320) + the
+        # packed weights once per step; the library's own per-launch accounting (`kernels[*].gbyte`, inputs + weights + outputs
+        # of every launch) is given beside it, and the dominant family's own rate.
+        act = MOBILENET_ACT_MELEMS * 1e6 * (S / 320.0) ** 2 * es * B
+        wbytes = float(eng.weights.numel())
+        alg = act + wbytes
+        ach = alg / (fwd_ms * 1e-3) / 1e9
+        lib_bytes = sum(f["bytes"] for f in prod)
+        roofline = {"bound": "hbm", "kernel": "whole forward (%d launches)" % sum(f["launches"] for f in prod), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "traffic_source": "no PMC pass in this run (profiles/r04_cfg4 holds the rocprofv3 passes)",
+                    "algorithmic_bytes_per_step": int(alg), "algorithmic": "%.1f M activation elements x %d B x batch %d + %.1f MB of weights" % (MOBILENET_ACT_MELEMS * (S / 320.0) ** 2, es, B, wbytes / 1e6),
+                    "per_launch_accounting_gbyte_per_step": round(lib_bytes / 1e9, 3),
+                    "mfma_side": {"achieved_tflops": round(gflop_step / fwd_ms, 2), "frac_of_%g" % PEAK_TFLOPS[args.dtype]: round(gflop_step / fwd_ms / PEAK_TFLOPS[args.dtype], 4)},
+                    "dominant_family": {"name": dom["name"], "ms": round(dom["ms"], 4), "gbyte_per_s": round(dom["bytes"] / 1e9 / (dom["ms"] * 1e-3), 1),
+                                        "tflop_per_s": round(dom["flops"] / 1e12 / (dom["ms"] * 1e-3), 1)}}
+
+    if rank != 0:
+        tdist.barrier()
+        return
+    line = {
+        "metric": "frames/sec/GPU @%dx%d %s" % (S, S, "TRN 4-frame clips, ssd4scale_vgg" if trn else "dualrefinedet_mobilenet"),
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE config #%d: %s %dx%d, %s, %s per GPU, forward%s, synthetic VOC-shaped frames + synthetic weights" % (
+                       args.config, name, S, S, args.dtype, ("%d clips x 4 frames (1 static + 4 temporal forwards + 4 Detect per clip)" % B) if trn else "batch %d" % B,
+                       "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
+                   "global_batch": world * frames_per_step, "parallelism": "%s-sharded x%d, no per-frame collective" % ("clip" if trn else "frame", world),
+                   "launch": "hipGraph replay" if args.graph else "eager", "resident_batches": NB},
+        "repetitions": {"n": len(reps), "reported": "median", "ms_per_step_min": round(reps[0] / args.steps * 1e3, 4), "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
+        "fps_per_gpu": round(fps / world, 2), "forward_only_ms_per_step": round(fwd_ms, 4), "forward_tflops": round(gflop_step / fwd_ms, 2),
+        "build": build, "roofline": roofline, "kernels": kernels,
+        "n_ranks_seen": world if world == 1 else int(torch.distributed.get_world_size()), "weights_broadcast_ms": round(bcast_ms, 2) if world > 1 else None,
+        "numa_pin": NUMA_PIN,
+    }
+    if trn:
+        line["clips_per_s"] = round(fps / FPC, 2)
+    # ---- parity of the timed dtype against the fp32 CPU oracle on one frame / one clip (decoded boxes, scores) ----
+    if not args.no_parity:
+        from oracle import net_ref
+        from oracle import oracle as orc
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        pr = pri.cpu().numpy()
+        if trn:
+            clip = synth.synth_frames(FPC, S, seed=5)
+            r_loc, r_conf, r_maps = net_ref.ssd4scale_vgg_forward(sd_s, clip[:1], 21, "test", False, False, ret_loc=True)
+            t_loc, t_conf, r_offs = net_ref.ssd4scale_vgg_forward(sd_t, clip[:1], 21, "test", False, True, ref_loc=r_maps, ret_off=True)
+            t1_loc, t1_conf = net_ref.ssd4scale_vgg_forward(sd_t, clip[1:2], 21, "test", False, True, offset_list=r_offs)[:2]
+            xc = torch.from_numpy(clip).to(dev)
+            g_loc, _, g_maps = stat(xc[:1], ret_loc=True)
+            gt_loc, gt_conf, g_offs = temp(xc[:1], ref_loc=g_maps, ret_off=True)
+            g1_loc, g1_conf = temp(xc[1:2], offset_list=g_offs)[:2]
+            def boxes(arm, loc):
+                return orc.decode(loc[0], orc.center_size(orc.decode(arm[0], pr)))
+            rb0, rb1 = boxes(r_loc.numpy(), t_loc.numpy()), boxes(r_loc.numpy(), t1_loc.numpy())
+            gb0, gb1 = boxes(g_loc.cpu().numpy(), gt_loc.cpu().numpy()), boxes(g_loc.cpu().numpy(), g1_loc.cpu().numpy())
+            eb = np.abs(np.concatenate([gb0 - rb0, gb1 - rb1]))
+            esc = np.abs(np.concatenate([gt_conf.cpu().numpy() - t_conf.numpy().reshape(gt_conf.shape), g1_conf.cpu().numpy() - t1_conf.numpy().reshape(g1_conf.shape)]))
+        else:
+            x1 = synth.synth_frames(1, S, seed=5)
+            r_arm, _, r_odm, r_conf = net_ref.drn_mobilenet_forward(sd, x1, 21, True)
+            o = net(torch.from_numpy(x1).to(dev))
+            rb = orc.decode(r_odm.numpy()[0], orc.center_size(orc.decode(r_arm.numpy()[0], pr)))
+            gb = orc.decode(o[2].cpu().numpy()[0], orc.center_size(orc.decode(o[0].cpu().numpy()[0], pr)))
+            eb = np.abs(gb - rb)
+            esc = np.abs(o[3].cpu().numpy() - r_conf.numpy().reshape(o[3].shape))
+        line["parity"] = {"reference": "fp32 CPU oracle (oracle/net_ref.py + oracle/tdrn_oracle.c)", "box_unit": "normalised image coordinates",
+                          args.dtype: {"box_linf": float(eb.max()), "box_p999": float(np.quantile(eb, 0.999)), "box_mean": float(eb.mean()),
+                                       "score_linf": float(esc.max()), "score_mean": float(esc.mean()),
+                                       "note": "all rows (rows next to a sampling discontinuity of the deformable heads included)"}}
+        line["box_linf"], line["score_linf"] = float(eb.max()), float(esc.max())
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import net_ref
+        from oracle import oracle as orc
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        pr = pri.cpu().numpy()
+        n = max(1, args.cpu_frames // (8 if trn else 2))
+        t0 = time.perf_counter()
+        done = 0
+        if trn:
+            sdt_s = {k: torch.from_numpy(v) for k, v in sd_s.items()}
+            sdt_t = {k: torch.from_numpy(v) for k, v in sd_t.items()}
+            clip = synth.synth_frames(FPC, S, seed=0)
+            while done < max(1, n // FPC):
+                r_loc, _, r_maps = net_ref.ssd4scale_vgg_forward(sdt_s, clip[:1], 21, "test", False, False, ret_loc=True)
+                offs = None
+                for f in range(FPC):
+                    if f == 0:
+                        l, c, offs = net_ref.ssd4scale_vgg_forward(sdt_t, clip[:1], 21, "test", False, True, ref_loc=r_maps, ret_off=True)
+                    else:
+                        l, c = net_ref.ssd4scale_vgg_forward(sdt_t, clip[f:f + 1], 21, "test", False, True, offset_list=offs)[:2]
+                    orc.detect(l.numpy(), c.numpy(), pr, r_loc.numpy(), (500, 375, 500, 375))
+                done += 1
+            frames_done = done * FPC
+        else:
+            sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+            xs = synth.synth_frames(1, S, seed=0)
+            while done < n:
+                arm, _, odm, conf = net_ref.drn_mobilenet_forward(sdt, xs, 21, True)
+                orc.detect(odm.numpy(), conf.numpy(), pr, arm.numpy(), (500, 375, 500, 375))
+                done += 1
+            frames_done = done
+        dtc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(frames_done / dtc, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                                "sample": "%d frames of the same workload, batch 1, fp32 (oracle/: torch-CPU convs + C deformable conv + C Detect), %.1f s" % (frames_done, dtc)}
+    print(json.dumps(line))
+    tdist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=11)           # evaluate.py:463 drops the first 11 frames
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--size", type=int, default=320)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = the headline)")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-detect", action="store_true", help="time the network forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the box / score error and detection-agreement blocks (oracle forwards on the host)")
@@ -254,8 +574,15 @@ def main():
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=96)      # ~16 s of CPU work on the GPU box host
     args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    for k in ("size", "dtype", "batch"):
+        if getattr(args, k) is None:
+            setattr(args, k, preset[k])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                                  # (does not return)
+    pin_rank_to_numa_node()                                     # before anything touches a GPU
+    if args.config in (4, 5):
+        return main_other(args)
 
     import torch
     from tdrn_amd import _lib
@@ -280,10 +607,13 @@ def main():
         sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
+    t_bc = time.perf_counter()
     if world > 1:
         eng = net.adopt_broadcast_weights(src=0, device=dev)     # the one collective: weights over xGMI
     else:
         eng = net.engine(dev)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t_bc) * 1e3                # (N > 1: rank 0's pack + the broadcast + every rank's adoption)
     B = args.batch
     NB = max(1, args.batches)
     # NB distinct batches, all resident in HBM before the timed region; step k runs batch k % NB
@@ -412,7 +742,7 @@ def main():
     # (before the other precisions' engines are created and destroyed: on ROCm 7.2 a hipGraph captured for the fp32 engine AFTER
     # other engines' graphs and events had been destroyed crashed in hipGraphLaunch)
     stream_blk = None
-    if world == 1 and NS == 1 and args.stream and not args.no_detect:
+    if NS == 1 and args.stream and not args.no_detect:          # (N > 1: every rank feeds its own GPU from its own pinned buffers)
         import numpy as np
         from tdrn_amd.stream import FrameStream
         NSL = max(3, NB)
@@ -426,19 +756,21 @@ def main():
         fs.drain()
         t_stream = []
         for _ in range(max(3, args.reps // 2)):
+            tdist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(args.steps):
                 fs.run()
             fs.drain()
-            t_stream.append(time.perf_counter() - t0)
+            tdist.barrier()
+            t_stream.append(tdist.max_over_ranks(time.perf_counter() - t0, dev))
         t_stream.sort()
         ts = t_stream[len(t_stream) // 2]
         fs.prime()
         got = fs.result(fs.run()).clone()
         want = fs.eager(fs.pinned_in(0).to(dev)).cpu()
-        stream_blk = {"frames_per_s": round(B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
-                      "vs_resident": round((B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
+        stream_blk = {"frames_per_s": round(world * B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
+                      "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
                       "copy_streams_picked": (fs.calibration or {}).get("picked"),
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
                       "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | caller's stream: one hipGraph per slot = tdrn_preprocess, net, Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
@@ -490,6 +822,11 @@ def main():
             "build": build,
             "roofline": roofline,
             "kernels": kernels,
+            # N > 1: what the first hardware run should tell -- how many ranks really joined, what the one collective cost, where
+            # each rank's feeder threads were pinned (tdrn_amd/dist.py pin_to_gpu_numa_node; rank 0's record)
+            "n_ranks_seen": world if world == 1 else int(torch.distributed.get_world_size()),
+            "weights_broadcast_ms": round(bcast_ms, 2) if world > 1 else None,
+            "numa_pin": NUMA_PIN,
         }
         if modes is not None:
             line["modes"] = modes

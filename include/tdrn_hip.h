@@ -40,6 +40,7 @@ extern "C" {
 #define TDRN_E_PARAM (-5)        /* unknown / missing / mis-shaped state_dict entry             */
 #define TDRN_E_STATE (-6)        /* call order (e.g. forward before weights were packed)        */
 #define TDRN_E_VALUE (-7)        /* Detect: nms_thresh <= 0 (layers/functions/detection.py:20)  */
+#define TDRN_E_DEVICE (-8)       /* a device-side hand-off of an earlier forward timed out: its outputs are invalid (tdrn_net_check) */
 
 TDRN_API const char *tdrn_version(void);
 TDRN_API const char *tdrn_error_string(int code);
@@ -223,11 +224,21 @@ typedef struct {
 #define TDRN_PLAN_ONE_STREAM    4   /* no side lanes: every launch on the caller's stream                              */
 #define TDRN_PLAN_NO_DEFORM_TS  8   /* deformable heads as the fused gather kernel (no transform-then-sample)           */
 #define TDRN_PLAN_CHAIN         16  /* the small top-of-pyramid layers as ONE queue-driven launch (measured slower: off by default) */
+/* Kernel-choice switches (tests/test_gpu_pin16.py holds the default plan bit-identical to each of them): */
+#define TDRN_PLAN_NO_CONV_PP    32  /* conv3x3_pp.hip's layers stay on the loader/consumer kernel conv3x3_patch.hip                */
+#define TDRN_PLAN_NO_PP_SK      64  /* conv3x3_pp.hip runs whole items only (no chained split)                                     */
+#define TDRN_PLAN_NO_CONV_PATCH 128 /* neither 3x3 direct-conv kernel: every conv on the generic implicit GEMM (conv_igemm.hip)    */
+#define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
+                                       consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 
 typedef struct tdrn_net tdrn_net;
 
 /* Builds the layer plan on the host (no device work). */
 TDRN_API int tdrn_net_create(const tdrn_net_config *cfg, tdrn_net **out);
+/* Frees the host-side plan.  It does NOT destroy the HIP streams / events the net used: they go back to a per-process,
+ * per-device pool and are reused by the next net on that device.  Reason (ROCm 7.2, csrc/dev/graph_destroy_repro.hip): a hipGraph
+ * captured AFTER streams / events that took part in an earlier capture had been destroyed crashed inside hipGraphLaunch.
+ * The caller must not destroy a net while a forward of it (or a graph captured from one) is still executing. */
 TDRN_API void tdrn_net_destroy(tdrn_net *net);
 
 /* state_dict interface: names and shapes are the reference's (entries ending in
@@ -269,6 +280,17 @@ typedef struct {
 TDRN_API int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *workspace,
                               size_t workspace_bytes, const tdrn_net_io *io, void *stream);
 
+/* Device-side failures.  Two launches hand data between workgroups through flags with BOUNDED polls (the chained split of
+ * conv3x3_pp.hip; the opt-in chain launch of conv_igemm.hip).  A poll that runs out never hangs the GPU and never passes
+ * silently: the kernel stores a code into a host-visible (pinned, device-mapped) status word owned by the net.
+ * tdrn_net_check returns TDRN_OK, or TDRN_E_DEVICE when any forward enqueued on this net SINCE THE LAST CHECK has reported such a
+ * failure (the word is cleared by the call); it does not synchronise -- call it after the stream (or the hipGraph replay) that
+ * ran the forward has been synchronised to learn about THAT forward.  tdrn_net_forward performs the same check on entry, so a
+ * failed forward makes the next tdrn_net_forward on the net return TDRN_E_DEVICE instead of launching ("never continue after
+ * an error"); the call after that runs again (flags and counters are re-zeroed by every forward).
+ * `detail` (or NULL) receives the raw word: bit 0 chained-split poll of conv3x3_pp.hip, bit 1 chain-launch poll. */
+TDRN_API int tdrn_net_check(tdrn_net *net, unsigned *detail);
+
 /* Per-kernel accounting of the LAST forward for bench.py's roofline line: algorithmic FLOPs
  * and bytes per kernel family, and (when profiling is enabled) hipEvent-measured time.
  * tdrn_net_profile(net, 1) makes the next forwards record an event pair around every launch and run
@@ -297,6 +319,28 @@ TDRN_API int tdrn_net_op_timeline(tdrn_net *net, float *start_ms, float *end_ms,
  * the oracle; not part of the hot path.  Tensors that a fused launch never materialises are not written: full-resolution
  * maps whose only reader is a fused max-pool, and -- in the 16-bit plans of the VGG trunks -- the first conv's output, which is
  * computed inside the next conv's loader (environment TDRN_FUSE_FIRST=0 keeps it as its own launch). */
+/* The plan's ops (test / debug access, like the tensors): what each launch computes and on which tensors, so that a test can
+ * recompute ANY stage from the stage's own materialised input (tests/test_gpu_pin16.py: every conv of the 16-bit plans against an
+ * fp64 convolution of its device input with the 16-bit-rounded folded weights).  Tensor fields are indices for
+ * tdrn_net_tensor_info / tdrn_net_read_tensor, -1 = none. */
+typedef struct {
+    int kind;          /* 0 first conv (Cin = 3), 1 dense conv, 2 ConvTranspose2d(2,2), 3 depthwise 3x3, 4 MaxPool2d(2,2), 5 L2Norm,
+                          6 1x1 offset conv, 7 deformable heads (loc + conf of one pyramid level), 8 anything else            */
+    int in, out, res;  /* input, output (-1: a head that writes arm_loc / odm_loc / conf), residual added before the ReLU       */
+    int pool;          /* conv: output of the MaxPool2d(2,2) fused into this launch (then `out` is not materialised), or -1    */
+    int off, y;        /* deformable heads: the fp32 offset tensor; the transform GEMM's output Y (16-bit one-group plans) or -1 */
+    int k, stride, pad, dil, relu, ceil_mode, splitk, groups;
+    int out_kind;      /* 0 tensor, 1 arm_loc, 2 odm_loc, 3 conf                                                               */
+    int level;         /* heads / offset convs: pyramid level                                                                  */
+    int n_branches, k2, pad2, off_c0[2]; /* deformable heads: 3x3 (+ 5x5) branch, first offset channel of each branch          */
+    int y_tap_major;   /* deformable heads with y >= 0: 1 = Y is [tap][B*H*W][80], 0 = [B*H*W][y channels] (column of tap t: (t/3)*256 + (t%3)*80) */
+    int fused_first;   /* conv: 1 = this launch also computes the first conv (its `in` is then not materialised)               */
+    char w[48], b[48], bn[48], w2[48], b2[48];  /* state_dict prefixes ('' = none): weight / bias owner / BatchNorm; second source (merged 5x5+3x3 heads; offset2;
+                          deformable heads: w = 3x3 loc, b = 3x3 conf, w2 = 5x5 loc, b2 = 5x5 conf)                             */
+} tdrn_op_info;
+TDRN_API int tdrn_net_op_count(const tdrn_net *net);
+TDRN_API int tdrn_net_op_info(const tdrn_net *net, int index, tdrn_op_info *out);
+
 TDRN_API int tdrn_net_tensor_count(const tdrn_net *net);
 TDRN_API int tdrn_net_tensor_info(const tdrn_net *net, int index, const char **label, int *C, int *H,
                                   int *W);

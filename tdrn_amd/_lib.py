@@ -28,6 +28,8 @@ class NetConfig(C.Structure):
 
 
 PLAN_NO_FUSE_FIRST, PLAN_NO_LATE_SIDE, PLAN_ONE_STREAM, PLAN_NO_DEFORM_TS, PLAN_CHAIN = 1, 2, 4, 8, 16      # tdrn_hip.h TDRN_PLAN_*
+PLAN_NO_CONV_PP, PLAN_NO_PP_SK, PLAN_NO_CONV_PATCH, PLAN_FAULT_HANDOFF = 32, 64, 128, 256
+E_DEVICE = -8
 
 
 class NetIO(C.Structure):
@@ -41,6 +43,17 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("flops", C.c_double),
                 ("bytes", C.c_double), ("ms", C.c_double)]
 
+
+class OpInfo(C.Structure):
+    _fields_ = [("kind", C.c_int), ("in_", C.c_int), ("out", C.c_int), ("res", C.c_int), ("pool", C.c_int), ("off", C.c_int),
+                ("y", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int), ("relu", C.c_int),
+                ("ceil_mode", C.c_int), ("splitk", C.c_int), ("groups", C.c_int), ("out_kind", C.c_int), ("level", C.c_int),
+                ("n_branches", C.c_int), ("k2", C.c_int), ("pad2", C.c_int), ("off_c0", C.c_int * 2), ("y_tap_major", C.c_int),
+                ("fused_first", C.c_int), ("w", C.c_char * 48), ("b", C.c_char * 48), ("bn", C.c_char * 48), ("w2", C.c_char * 48),
+                ("b2", C.c_char * 48)]
+
+
+OP_KINDS = ("first_conv", "conv", "conv_transpose", "depthwise", "maxpool", "l2norm", "offset_conv", "deform_heads", "other")
 
 _lib = None
 
@@ -83,6 +96,9 @@ _SIGS = {
     "tdrn_net_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tdrn_net_adopt_weights": (C.c_int, [C.c_void_p]),
     "tdrn_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(NetIO), C.c_void_p]),
+    "tdrn_net_check": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
+    "tdrn_net_op_count": (C.c_int, [C.c_void_p]),
+    "tdrn_net_op_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(OpInfo)]),
     "tdrn_net_tensor_count": (C.c_int, [C.c_void_p]),
     "tdrn_net_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),

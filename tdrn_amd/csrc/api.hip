@@ -50,7 +50,7 @@ int deform_plan(int N, int Cin, int H, int W, int Cout, int kH, int kW, int dH, 
 
 extern "C" {
 
-const char *tdrn_version(void) { return "tdrn_hip 0.3 (gfx950)"; }
+const char *tdrn_version(void) { return "tdrn_hip 0.4 (gfx950)"; }
 
 const char *tdrn_error_string(int code)
 {
@@ -63,6 +63,7 @@ const char *tdrn_error_string(int code)
         case TDRN_E_PARAM: return "unknown, missing or mis-shaped parameter";
         case TDRN_E_STATE: return "invalid call order";
         case TDRN_E_VALUE: return "nms_threshold must be non negative.";
+        case TDRN_E_DEVICE: return "a device-side hand-off of an earlier forward timed out (its outputs are invalid)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }

@@ -793,6 +793,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 // ---------------------------------------------------------------------------------------------
 int patch_conv_supported(const ConvArgs &a)
 {
+    if (a.kdisable & 4) return 0;
     if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1) return 0;
     if (a.phases != 1 || a.out_f32 || a.res) return 0;
     if (a.Ho != a.H || a.Wo != a.W) return 0;

@@ -64,6 +64,9 @@ struct PPParams {
     // word per workgroup; null = whole items only
     float *sk_slab;
     unsigned *sk_flag;
+    unsigned *status;              // host-visible status word (or null): <- 1 when a poll of the chained split runs out
+    unsigned poll_max;             // bound of that poll (iterations of load + s_sleep 8)
+    int fault;                     // fault injection: the producer never raises its flag
 };
 
 namespace {
@@ -461,10 +464,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
         }
         if (wave == 0) {
             if (lane == 0) {
+                // Bounded poll.  Progress argument: the producer (workgroup my_wg - 1) writes this slab FIRST (its unfinished last
+                // item runs first) and I read it LAST (behind all my other items), and all 256 workgroups of the launch are
+                // resident at once (grid == 256 == one per CU; the dispatcher starts lower block indices first when a concurrent
+                // side-lane kernel holds CUs, so a producer is never started after its consumer).  Should the poll run out all
+                // the same, the forward is REPORTED failed through the host-visible status word (tdrn_net_check; the item is then
+                // finished from whatever the slab holds, so the launch still ends) -- and the flag is NOT reset: a late producer
+                // would leave it raised for good; the next forward's memset clears it.
                 unsigned spins = 0;
-                while (__hip_atomic_load(p.sk_flag + (my_wg - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 20))
+                bool seen;
+                while (!(seen = __hip_atomic_load(p.sk_flag + (my_wg - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) && ++spins < p.poll_max)
                     __builtin_amdgcn_s_sleep(8);
-                __hip_atomic_store(p.sk_flag + (my_wg - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (its only reader)
+                if (seen) __hip_atomic_store(p.sk_flag + (my_wg - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (its only reader)
+                else if (p.status) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
         if (wave == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(p.sk_flag + my_wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && !p.fault) __hip_atomic_store(p.sk_flag + my_wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
@@ -733,7 +745,7 @@ size_t conv_pp_sk_bytes() { return 1024 + (size_t)256 * 8 * 32 * 64 * 16; }
 // the layers this kernel takes over from conv3x3_patch.hip: 16-bit, >= 2 channel chunks, couts in whole 256-groups
 int pp_conv_supported(const ConvArgs &a)
 {
-    if (!conv_pp_enabled()) return 0;
+    if (!conv_pp_enabled() || (a.kdisable & 1)) return 0;
     if (a.dtype == TDRN_F32 || a.fuse_x) return 0;
     // (Cin = 128 -- two chunks, 18 steps per item -- stays with conv3x3_patch.hip: the per-item cost of this kernel, drain +
     // epilogue + re-stagger, weighs 10 % there: 125 vs 116 us on conv3_1 in the net)
@@ -783,7 +795,9 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
     // chained split when it shortens the launch: a full grid, more than one item per workgroup, and an item count that does
     // not divide evenly (otherwise whole items are already balanced); the choice changes no output bit
     p.sk_slab = nullptr; p.sk_flag = nullptr;
-    if (a.sk_ws && conv_pp_sk_enabled() && grid == 256 && p.items > 256 && p.items % 256 != 0) {
+    p.status = a.status; p.fault = a.fault_handoff; p.poll_max = a.fault_handoff ? (1u << 10) : (1u << 20);
+    // (grid == 256: every workgroup of the launch is resident at once, see the poll in begin_acc)
+    if (a.sk_ws && conv_pp_sk_enabled() && !(a.kdisable & 2) && grid == 256 && p.items > 256 && p.items % 256 != 0) {
         p.sk_flag = (unsigned *)a.sk_ws;
         p.sk_slab = (float *)((char *)a.sk_ws + 1024);
         if (!a.sk_flags_zero) TDRN_HIP_TRY(hipMemsetAsync(p.sk_flag, 0, 1024, s));

@@ -671,6 +671,7 @@ struct ChainStage {
 struct ChainParams {
     int n, total;
     unsigned *ctr;                              // [0] queue head, [1 + 2s] tiles done of stage s, [2 + 2s] reduce tasks done; zero on entry
+    unsigned *status;                           // host-visible status words (or null): [1] <- 1 when a bounded wait runs out (tdrn_net_check)
     ChainStage st[kChainMax];
 };
 static_assert(sizeof(ChainParams) <= 4096, "kernel argument block");
@@ -702,13 +703,14 @@ __global__ __launch_bounds__(256) void conv_chain_kernel(const ChainParams cp)
     __shared__ int s_task;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // wave 0, all lanes (the same address: one request): poll until *c >= n.  Bounded: a wait that runs out -- it never should --
-    // is counted in ctr[40] and its task kept in ctr[41] for the host to see.
+    // is counted in ctr[40], its task kept in ctr[41], and REPORTED through the host-visible status word (tdrn_net_check).
     auto wait_for = [&](const unsigned *c, unsigned n, int task) {
         unsigned spins = 0;
         while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < n) {
             if (++spins >= (1u << 18)) {
                 (void)lane0_atomic_add(cp.ctr + 40, 1u);
                 (void)lane0_atomic_add(cp.ctr + 41, (unsigned)task);
+                if (cp.status) __hip_atomic_store(cp.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (all lanes: the same word, the same value)
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
@@ -770,12 +772,13 @@ int conv_chain_supported(const ConvArgs &a)
     return 1;
 }
 
-int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s)
+int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s, unsigned *status)
 {
     if (!layers || n <= 0 || n > kChainMax || !ctr) return TDRN_E_ARG;
     ChainParams cp;
     cp.n = n;
     cp.ctr = ctr;
+    cp.status = status;
     int task0 = 0;
     const int dtype = layers[0].a.dtype;
     for (int i = 0; i < n; ++i) {

@@ -11,6 +11,8 @@
 // Up to two branches (the 3x3 and the 5x5 "multihead" heads, model/dualrefinedet_vggbn.py:181-187)
 // and several heads stacked along Cout (loc = 12, conf = 63 channels) share one launch: the sum
 // l(ob,f) + l2(ob,f2) is just a longer K loop, and loc/conf are column segments of the same GEMM.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace tdrn {
@@ -694,6 +696,16 @@ int deform_sample_supported(const DeformArgs &a)
     return taps <= 34 ? taps : 0;
 }
 int deform_sample_cols(int taps) { return ((taps + 2) / 3) * 256; }
+int deform_ts_max_batch(int H, int W, int ycs, int taps)
+{
+    // launch_ygemm: taps * M * 160 < 2^32 (tap-major) ; launch_deform_sample_multi: M * ycs * 2 < 2^32 ; M < 2^31
+    const long long hw = (long long)H * W;
+    const long long per = std::max((long long)taps * 160, (long long)ycs * 2) * hw;
+    long long b = ((1ll << 32) - 1) / per;
+    const long long bm = ((1ll << 31) - 1) / hw;
+    b = b < bm ? b : bm;
+    return (int)(b > (1 << 20) ? (1 << 20) : b);
+}
 
 // y[i]: the level's Y tensor ([B*H*W][ycs[i]], net dtype), computed by the caller's 1x1 GEMM with the branches' taps in order
 int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s, int tap_major)

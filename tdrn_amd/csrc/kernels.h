@@ -42,6 +42,13 @@ struct ConvArgs {
     int max_wgs = 0;                // patch kernel: > 0 caps the persistent grid (a multiple of 8), leaving CUs to concurrent lanes
     void *sk_ws = nullptr;          // conv3x3_pp.hip: scratch of conv_pp_sk_bytes() for the chained split (one launch at a time), or null
     bool sk_flags_zero = false;     // the first 1024 bytes of sk_ws are zero on entry (every launch leaves them zero): no memset node
+    // kernel-choice switches of this launch (tdrn_net_config.plan_flags TDRN_PLAN_NO_CONV_PP / _NO_PP_SK / _NO_CONV_PATCH):
+    // bit 0: not conv3x3_pp.hip, bit 1: no chained split, bit 2: neither 3x3 direct-conv kernel.  Same output bits either way.
+    int kdisable = 0;
+    // host-visible status words (pinned, device-mapped; tdrn_net_check): [0] <- 1 when a chained-split poll runs out,
+    // [1] <- 1 when a poll of the chain launch does.  Null: a timed-out poll is not reported (dev harness only).
+    unsigned *status = nullptr;
+    int fault_handoff = 0;          // fault injection (tests): producers never raise their flag, the polls are short
 };
 int launch_conv(const ConvArgs &a, hipStream_t s);
 // Several small dependent layers in ONE launch (conv_igemm.hip, conv_chain_kernel): layer i may depend on up to two EARLIER
@@ -51,7 +58,7 @@ struct ChainLayer { ConvArgs a; int dep[2] = {-1, -1}; };
 int conv_chain_supported(const ConvArgs &a);
 int conv_chain_max_layers();
 size_t conv_chain_ctr_bytes();
-int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s);
+int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s, unsigned *status = nullptr);
 int conv_splitk_choice(const ConvArgs &a);          // 1 = no split
 size_t conv_splitk_bytes(const ConvArgs &a, int splits);
 // warp-specialised 3x3/s1/p1 kernel (conv3x3_patch.hip); out_pool = optional fused MaxPool2d(2,2) output
@@ -148,6 +155,8 @@ int deform_sample_cols(int taps);
 // column of tap t's 80 outputs in the transform GEMM's output: three taps per 256-column slice (a slice of ygemm_k256 then holds
 // whole taps only; columns 240..255 of every slice are zero padding)
 constexpr int deform_y_col(int tap) { return (tap / 3) * 256 + (tap % 3) * 80; }
+// the largest batch whose Y ([taps][B*H*W][80] tap-major or [B*H*W][ycs]) stays below the kernels' 32-bit byte offsets
+int deform_ts_max_batch(int H, int W, int ycs, int taps);
 int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, const int *ycs, int n, hipStream_t s, int tap_major = 0);
 // Y = X[M][256] * Wt[N][256]^T in the net dtype, weights held in registers (deform.hip); N % 256 == 0
 int ygemm_supported(int Cin, int ycols, int dtype);

@@ -71,37 +71,61 @@ struct Op {
 // with bench.py's three engines: a 16-bit engine destroyed, then the fp32 engine's step captured and replayed).  A net takes
 // them from the pool and hands them back in tdrn_net_destroy; nothing in the pool is ever in use by two nets at a time.
 namespace pool {
+// (keyed by device: a net created while device 1 is current must not inherit device 0's handles)
 std::mutex mu;
-std::vector<hipStream_t> streams;
-std::vector<hipEvent_t> events;
-std::vector<hipEvent_t> timing_events;
-int get_stream(hipStream_t *s)
+std::map<int, std::vector<hipStream_t>> streams;
+std::map<int, std::vector<hipEvent_t>> events;
+std::map<int, std::vector<hipEvent_t>> timing_events;
+std::vector<unsigned *> status_words;      // pinned, device-mapped host memory (visible to every device): 64 bytes each
+int cur_dev()
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+int get_stream(int dev, hipStream_t *s)
 {
     {
         std::lock_guard<std::mutex> g(mu);
-        if (!streams.empty()) { *s = streams.back(); streams.pop_back(); return TDRN_OK; }
+        auto &v = streams[dev];
+        if (!v.empty()) { *s = v.back(); v.pop_back(); return TDRN_OK; }
     }
     return hip_status(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
 }
-int get_event(hipEvent_t *e)
+int get_event(int dev, hipEvent_t *e)
 {
     {
         std::lock_guard<std::mutex> g(mu);
-        if (!events.empty()) { *e = events.back(); events.pop_back(); return TDRN_OK; }
+        auto &v = events[dev];
+        if (!v.empty()) { *e = v.back(); v.pop_back(); return TDRN_OK; }
     }
     return hip_status(hipEventCreateWithFlags(e, hipEventDisableTiming));
 }
-int get_timing_event(hipEvent_t *e)
+int get_timing_event(int dev, hipEvent_t *e)
 {
     {
         std::lock_guard<std::mutex> g(mu);
-        if (!timing_events.empty()) { *e = timing_events.back(); timing_events.pop_back(); return TDRN_OK; }
+        auto &v = timing_events[dev];
+        if (!v.empty()) { *e = v.back(); v.pop_back(); return TDRN_OK; }
     }
     return hip_status(hipEventCreate(e));
 }
-void put_timing_event(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); timing_events.push_back(e); } }
-void put_stream(hipStream_t s) { if (s) { std::lock_guard<std::mutex> g(mu); streams.push_back(s); } }
-void put_event(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); events.push_back(e); } }
+int get_status(unsigned **w)
+{
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!status_words.empty()) { *w = status_words.back(); status_words.pop_back(); memset(*w, 0, 64); return TDRN_OK; }
+    }
+    void *p = nullptr;
+    TDRN_HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable));
+    memset(p, 0, 64);
+    *w = (unsigned *)p;
+    return TDRN_OK;
+}
+void put_timing_event(int dev, hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); timing_events[dev].push_back(e); } }
+void put_stream(int dev, hipStream_t s) { if (s) { std::lock_guard<std::mutex> g(mu); streams[dev].push_back(s); } }
+void put_event(int dev, hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(mu); events[dev].push_back(e); } }
+void put_status(unsigned *w) { if (w) { std::lock_guard<std::mutex> g(mu); status_words.push_back(w); } }
 }  // namespace pool
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
@@ -150,6 +174,9 @@ struct tdrn_net {
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
     int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
+    int dev = -1;                       // the device the pooled handles below belong to (the one current at the first forward)
+    unsigned *status = nullptr;         // host-visible status words (pinned; tdrn_net_check): [0] chained split, [1] chain launch
+    int kdisable = 0, fault_handoff = 0;
     hipStream_t side[kLanes - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_zero = nullptr, ev_skz = nullptr, ev_join[kLanes - 1] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tensor_ev;
@@ -634,6 +661,9 @@ struct tdrn_net {
     int build()
     {
         es = dtype_bytes(cfg.dtype);
+        kdisable = ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PP) ? 1 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PP_SK) ? 2 : 0) |
+                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0);
+        fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
         if (cfg.size < 128 || cfg.size > 1280 || cfg.size % 64 != 0) return TDRN_E_ARG;
@@ -677,7 +707,7 @@ struct tdrn_net {
             const char *fe = getenv("TDRN_FUSE_FIRST");
             const bool fuse_on = fe ? atoi(fe) != 0 : !(cfg.plan_flags & TDRN_PLAN_NO_FUSE_FIRST);
             fuse_first = -1;
-            if (fuse_on && cfg.dtype != TDRN_F32 && conv_patch_enabled() && ops.size() > 1 && ops[0].kind == OP_FIRST &&
+            if (fuse_on && cfg.dtype != TDRN_F32 && conv_patch_enabled() && !(kdisable & 4) && ops.size() > 1 && ops[0].kind == OP_FIRST &&
                 ops[1].kind == OP_CONV && ops[0].stride == 1 && tensors[ops[0].out].Cpad == 64) {
                 const Op &c = ops[1];
                 const Tensor &ti = tensors[ops[0].out];
@@ -709,6 +739,7 @@ struct tdrn_net {
                 a.B = splitk_ref_batch; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
                 a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
                 a.phases = o.phases; a.dtype = cfg.dtype; a.out_f32 = o.out_kind != OUT_TENSOR;
+                a.kdisable = kdisable;
                 o.splitk = conv_splitk_choice(a);
                 a.o_cs = o.out_kind == OUT_TENSOR ? tensors[o.out].Cpad : 0;
                 a.o_rs = (long long)a.Wo * a.o_cs; a.o_bs = (long long)a.Ho * a.Wo * a.o_cs;
@@ -818,15 +849,15 @@ struct tdrn_net {
     {
         if (lanes_ready) return TDRN_OK;
         for (int i = 0; i < kLanes - 1; ++i) {
-            TDRN_TRY(pool::get_stream(&side[i]));
-            TDRN_TRY(pool::get_event(&ev_join[i]));
+            TDRN_TRY(pool::get_stream(dev, &side[i]));
+            TDRN_TRY(pool::get_event(dev, &ev_join[i]));
         }
-        TDRN_TRY(pool::get_event(&ev_fork));
-        TDRN_TRY(pool::get_event(&ev_zero));
-        TDRN_TRY(pool::get_event(&ev_skz));
+        TDRN_TRY(pool::get_event(dev, &ev_fork));
+        TDRN_TRY(pool::get_event(dev, &ev_zero));
+        TDRN_TRY(pool::get_event(dev, &ev_skz));
         tensor_ev.assign(tensors.size(), nullptr);
         for (size_t t = 0; t < tensors.size(); ++t)
-            if (tensor_shared[t]) TDRN_TRY(pool::get_event(&tensor_ev[t]));
+            if (tensor_shared[t]) TDRN_TRY(pool::get_event(dev, &tensor_ev[t]));
         lanes_ready = true;
         return TDRN_OK;
     }
@@ -1031,6 +1062,18 @@ struct tdrn_net {
         const int B = io->batch;
         if (ws_bytes < ws_per_sample * (size_t)B + ws_fixed) return TDRN_E_WORKSPACE;
         if (!io->conf) return TDRN_E_ARG;
+        // a net's pooled streams / events belong to ONE device: the one current at its first forward
+        {
+            const int d = pool::cur_dev();
+            if (dev < 0) dev = d;
+            else if (dev != d) return TDRN_E_STATE;
+        }
+        // "never continue after an error": a forward whose device-side hand-off timed out makes the NEXT call fail
+        // (no synchronisation here: the word is host memory the kernels store to)
+        if (ws_fixed) {
+            if (!status) TDRN_TRY(pool::get_status(&status));
+            TDRN_TRY(check_status(nullptr));
+        }
         const bool is_drn = cfg.model == TDRN_DRN_VGGBN || cfg.model == TDRN_DRN_MOBILENET || cfg.model == TDRN_REFINEDET_VGG;
         const bool has_arm = cfg.model != TDRN_REFINEDET_VGG || cfg.use_refine;
         if (is_drn && !io->odm_loc) return TDRN_E_ARG;
@@ -1042,7 +1085,7 @@ struct tdrn_net {
         if (profile && ev.size() < 2 * ops.size()) {
             const size_t old = ev.size();
             ev.resize(2 * ops.size());
-            for (size_t i = old; i < ev.size(); ++i) TDRN_TRY(pool::get_timing_event(&ev[i]));
+            for (size_t i = old; i < ev.size(); ++i) TDRN_TRY(pool::get_timing_event(dev, &ev[i]));
         }
         ev_stat.clear();
         ev_op.clear();
@@ -1118,6 +1161,7 @@ struct tdrn_net {
             a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = o.hw >> 16; a.Wo = o.hw & 0xffff;
             a.Cout = o.Cout; a.Npad = o.Npad; a.kh = a.kw = o.k; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil;
             a.relu = o.relu; a.phases = o.phases; a.dtype = cfg.dtype;
+            a.kdisable = kdisable; a.status = status; a.fault_handoff = fault_handoff;
             if (o.out_kind == OUT_TENSOR) {
                 const Tensor &to = tensors[o.out];
                 a.out = tptr(ws, o.out, B);
@@ -1151,7 +1195,7 @@ struct tdrn_net {
         int ts_tap_major = ts_tap_env ? 1 : 0;
         for (const Op &d : ops)
             if (d.kind == OP_DEFORM && d.y_t >= 0 && !ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) ts_tap_major = 0;
-        int ts_cs[4] = {0, 0, 0, 0};
+        int ts_cs[4] = {0, 0, 0, 0}, ts_op[4] = {-1, -1, -1, -1};
         int n_dargs = 0;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &o = ops[oi];
@@ -1205,7 +1249,7 @@ struct tdrn_net {
                             TDRN_HIP_TRY(hipStreamWaitEvent(s0, ev_skz, 0));
                             skz_pending = false;
                         }
-                        rc = launch_conv_chain(cl, n, (unsigned *)tail, s);
+                        rc = launch_conv_chain(cl, n, (unsigned *)tail, s, status);
                         if (rc == TDRN_OK && lanes)
                             for (int k = 1; k < n; ++k) {
                                 const int t = ops[chain_ops[k]].out;
@@ -1296,24 +1340,52 @@ struct tdrn_net {
                     a.out1 = io->conf + (size_t)scale_off[o.scale] * C; a.o1_bs = (long long)P * C; a.o1_ps = 3 * C;
                     a.split = 12; a.dtype = cfg.dtype;
                     dargs[n_dargs++] = a;
-                    if (o.y_t >= 0) {           // transform: Y = X * W_taps (1x1 implicit GEMM, net dtype out)
-                        ConvArgs g;
-                        g.in = a.in; g.w = wb + o.wt_off; g.bias = (const float *)(wb + o.bt_off); g.zero_page = wb;
-                        g.B = B; g.H = ti.H; g.W = ti.W; g.Cin = o.Cin; g.Ho = ti.H; g.Wo = ti.W; g.Cout = o.y_cols; g.Npad = o.y_cols;
-                        g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0; g.phases = 1; g.dtype = cfg.dtype;
-                        g.out = tptr(ws, o.y_t, B);
-                        g.o_cs = o.y_cols; g.o_rs = (long long)ti.W * o.y_cols; g.o_bs = (long long)ti.H * ti.W * o.y_cols;
-                        int taps = 0;
-                        for (int k = 0; k < o.n_branches; ++k) taps += a.br[k].kh * a.br[k].kw;
-                        if (ygemm_supported(o.Cin, o.y_cols, cfg.dtype))
-                            rc = launch_ygemm(g.in, g.w, g.out, (long long)B * ti.H * ti.W, o.y_cols, o.y_cols, cfg.dtype, s, ts_tap_major ? taps : 0);
-                        else
-                            rc = launch_conv(g, s);
-                        if (rc != TDRN_OK) break;
-                        ts_y[n_dargs - 1] = g.out; ts_cs[n_dargs - 1] = o.y_cols;
-                    }
-                    if (!deform_batched && o.y_t >= 0) {   // ... then sample: all pyramid levels in one launch
-                        rc = launch_deform_sample_multi(dargs, ts_y, ts_cs, n_dargs, s, ts_tap_major);
+                    if (o.y_t >= 0) ts_op[n_dargs - 1] = (int)oi;
+                    if (!deform_batched && o.y_t >= 0) {
+                        // transform: Y = X * W_taps (1x1 GEMM, net dtype out) per level, then sample: all pyramid levels in one
+                        // launch.  Y is addressed with 32-bit byte offsets (deform.hip), so a batch whose Y would pass 4 GiB at
+                        // some level runs as several batch RANGES through the same Y buffers, one (transforms, sample) group per
+                        // range on this stream -- per-frame arithmetic untouched (DRN at 512 px: 171 frames and up; at 320 px: 437).
+                        int Bc = B;
+                        for (int i = 0; i < n_dargs; ++i) {
+                            const Op &d = ops[ts_op[i]];
+                            int taps = 0;
+                            for (int k = 0; k < d.n_branches; ++k) taps += dargs[i].br[k].kh * dargs[i].br[k].kw;
+                            const int fit = deform_ts_max_batch(dargs[i].H, dargs[i].W, d.y_cols, taps);
+                            Bc = fit < Bc ? fit : Bc;
+                        }
+                        if (Bc < 1) { rc = TDRN_E_UNSUPPORTED; break; }
+                        for (int b0 = 0; b0 < B && rc == TDRN_OK; b0 += Bc) {
+                            const int nb = B - b0 < Bc ? B - b0 : Bc;
+                            DeformArgs ca[4];
+                            for (int i = 0; i < n_dargs && rc == TDRN_OK; ++i) {
+                                const Op &d = ops[ts_op[i]];
+                                DeformArgs &c = ca[i];
+                                c = dargs[i];
+                                const size_t px0 = (size_t)b0 * c.H * c.W;
+                                c.B = nb;
+                                c.in = (const char *)c.in + px0 * c.Cin * es;
+                                for (int k = 0; k < c.n_branches; ++k) c.br[k].off += px0 * c.br[k].off_stride;
+                                c.out0 += (size_t)b0 * c.o0_bs;
+                                c.out1 += (size_t)b0 * c.o1_bs;
+                                int taps = 0;
+                                for (int k = 0; k < c.n_branches; ++k) taps += c.br[k].kh * c.br[k].kw;
+                                void *ybuf = tptr(ws, d.y_t, B);
+                                if (ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) {
+                                    rc = launch_ygemm(c.in, wb + d.wt_off, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, cfg.dtype, s, ts_tap_major ? taps : 0);
+                                } else {
+                                    ConvArgs g;
+                                    g.in = c.in; g.w = wb + d.wt_off; g.bias = (const float *)(wb + d.bt_off); g.zero_page = wb;
+                                    g.B = nb; g.H = c.H; g.W = c.W; g.Cin = d.Cin; g.Ho = c.H; g.Wo = c.W; g.Cout = d.y_cols; g.Npad = d.y_cols;
+                                    g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0; g.phases = 1; g.dtype = cfg.dtype;
+                                    g.out = ybuf; g.kdisable = kdisable;
+                                    g.o_cs = d.y_cols; g.o_rs = (long long)c.W * d.y_cols; g.o_bs = (long long)c.H * c.W * d.y_cols;
+                                    rc = launch_conv(g, s);
+                                }
+                                ts_y[i] = ybuf; ts_cs[i] = d.y_cols;
+                            }
+                            if (rc == TDRN_OK) rc = launch_deform_sample_multi(ca, ts_y, ts_cs, n_dargs, s, ts_tap_major);
+                        }
                         n_dargs = 0;
                         break;
                     }
@@ -1358,6 +1430,18 @@ struct tdrn_net {
             }
         }
         return join.run();
+    }
+
+    int check_status(unsigned *detail)
+    {
+        unsigned d = 0;
+        if (status) {
+            volatile unsigned *w = status;
+            d = (w[0] ? 1u : 0u) | (w[1] ? 2u : 0u);
+            if (d) { w[0] = 0; w[1] = 0; }
+        }
+        if (detail) *detail = d;
+        return d ? TDRN_E_DEVICE : TDRN_OK;
     }
 
     int collect_stats(tdrn_kernel_stat *out, int max_entries)
@@ -1406,15 +1490,17 @@ int tdrn_net_create(const tdrn_net_config *cfg, tdrn_net **out)
 void tdrn_net_destroy(tdrn_net *net)
 {
     if (!net) return;
-    for (hipEvent_t e : net->ev) pool::put_timing_event(e);         // (timing events of the profiling passes: never captured; pooled like the rest)
-    for (hipEvent_t e : net->tensor_ev) pool::put_event(e);
+    const int d = net->dev;
+    for (hipEvent_t e : net->ev) pool::put_timing_event(d, e);         // (timing events of the profiling passes: never captured; pooled like the rest)
+    for (hipEvent_t e : net->tensor_ev) pool::put_event(d, e);
     for (int i = 0; i < tdrn_net::kLanes - 1; ++i) {
-        pool::put_event(net->ev_join[i]);
-        pool::put_stream(net->side[i]);
+        pool::put_event(d, net->ev_join[i]);
+        pool::put_stream(d, net->side[i]);
     }
-    pool::put_event(net->ev_fork);
-    pool::put_event(net->ev_zero);
-    pool::put_event(net->ev_skz);
+    pool::put_event(d, net->ev_fork);
+    pool::put_event(d, net->ev_zero);
+    pool::put_event(d, net->ev_skz);
+    pool::put_status(net->status);
     delete net;
 }
 
@@ -1476,6 +1562,47 @@ int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *workspace, si
 {
     if (!net) return TDRN_E_ARG;
     return net->forward(weights_dev, workspace, workspace_bytes, io, (hipStream_t)stream);
+}
+
+int tdrn_net_check(tdrn_net *net, unsigned *detail)
+{
+    if (!net) return TDRN_E_ARG;
+    return net->check_status(detail);
+}
+
+int tdrn_net_op_count(const tdrn_net *net) { return net ? (int)net->ops.size() : TDRN_E_ARG; }
+
+int tdrn_net_op_info(const tdrn_net *net, int index, tdrn_op_info *out)
+{
+    if (!net || !out || index < 0 || index >= (int)net->ops.size()) return TDRN_E_ARG;
+    const Op &o = net->ops[index];
+    memset(out, 0, sizeof(*out));
+    switch (o.kind) {
+        case OP_FIRST: out->kind = 0; break;
+        case OP_CONV: out->kind = o.phases == 4 ? 2 : 1; break;
+        case OP_DW: out->kind = 3; break;
+        case OP_POOL: out->kind = 4; break;
+        case OP_L2NORM: out->kind = 5; break;
+        case OP_OFFSET: out->kind = 6; break;
+        case OP_DEFORM: out->kind = 7; break;
+        default: out->kind = 8; break;
+    }
+    out->in = o.in; out->out = o.out; out->res = o.res; out->pool = o.pool_t; out->off = o.off_t; out->y = o.y_t;
+    out->k = o.k; out->stride = o.stride; out->pad = o.pad; out->dil = o.dil; out->relu = o.relu; out->ceil_mode = o.ceil;
+    out->splitk = o.splitk; out->groups = o.G; out->out_kind = o.out_kind; out->level = o.scale;
+    out->n_branches = o.n_branches; out->k2 = o.k2; out->pad2 = o.pad2; out->off_c0[0] = o.off_c0[0]; out->off_c0[1] = o.off_c0[1];
+    if (o.kind == OP_DEFORM && o.y_t >= 0) {
+        static int tm = -1;
+        if (tm < 0) { const char *e = getenv("TDRN_Y_TAP_MAJOR"); tm = e ? atoi(e) : 1; }
+        bool all = tm != 0;
+        for (const Op &d : net->ops)
+            if (d.kind == OP_DEFORM && d.y_t >= 0 && !ygemm_supported(d.Cin, d.y_cols, net->cfg.dtype)) all = false;
+        out->y_tap_major = all ? 1 : 0;
+    }
+    out->fused_first = (index == net->fuse_first) ? 1 : 0;
+    auto cp = [](char *d, const std::string &v) { strncpy(d, v.c_str(), 47); };
+    cp(out->w, o.w); cp(out->b, o.b); cp(out->bn, o.bn); cp(out->w2, o.w2); cp(out->b2, o.b2);
+    return TDRN_OK;
 }
 
 int tdrn_net_tensor_count(const tdrn_net *net) { return net ? (int)net->tensors.size() : TDRN_E_ARG; }

@@ -31,6 +31,86 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every AMD GPU of this host in PCI-address order (= the HIP enumeration order on a default ROCm setup),
+    read from sysfs only -- nothing here touches the GPU or the HIP runtime.  -1 where the platform reports none."""
+    base = os.path.join(sysfs, "bus", "pci", "devices")
+    out = []
+    try:
+        devs = sorted(os.listdir(base))
+    except OSError:
+        return out
+    for bdf in devs:
+        d = os.path.join(base, bdf)
+        try:
+            vendor = open(os.path.join(d, "vendor")).read().strip()
+            cls = open(os.path.join(d, "class")).read().strip()
+        except OSError:
+            continue
+        # AMD, display controller (0x03xxxx) or processing accelerator (0x12xxxx: Instinct parts)
+        if vendor != "0x1002" or not (cls.startswith("0x03") or cls.startswith("0x12")):
+            continue
+        try:
+            node = int(open(os.path.join(d, "numa_node")).read().strip())
+        except (OSError, ValueError):
+            node = -1
+        out.append((bdf, node))
+    return out
+
+
+def pin_to_gpu_numa_node(local_rank, world, sysfs="/sys", apply=True):
+    """CPU affinity of this rank = the CPUs of its GPU's NUMA node (at 8 x ~10k frames/s the host feeds
+    8 x 18 MB per step over PCIe from 8 Python feeders; a feeder on the far socket pays the inter-socket hop on every
+    pinned-buffer write and H2D descriptor).  Call BEFORE the first GPU call of the process (the runtime's helper threads
+    inherit the mask).  The GPU is chosen as the local_rank-th AMD device in PCI order, through HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES when they are plain index lists.  Falls back to an even split of the CPUs this process may use
+    when sysfs names no node.  Returns a description for the bench line."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return {"pinned": False, "reason": "no sched_getaffinity on this platform"}
+    gpus = gpu_numa_nodes(sysfs)
+    idx = local_rank
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                idx = [int(t) for t in v.split(",")][local_rank]
+            except (ValueError, IndexError):
+                pass
+            break
+    node, cpus, how = -1, None, None
+    if 0 <= idx < len(gpus):
+        node = gpus[idx][1]
+    if node >= 0:
+        try:
+            cpus = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")).read()) & allowed
+            how = "numa node %d of GPU %s" % (node, gpus[idx][0])
+        except OSError:
+            cpus = None
+    if not cpus:
+        order = sorted(allowed)
+        per = max(1, len(order) // max(1, world))
+        cpus = set(order[(local_rank % max(1, world)) * per:(local_rank % max(1, world) + 1) * per]) or allowed
+        how = "even split of %d usable CPUs over %d ranks (sysfs names no NUMA node for the GPU)" % (len(order), world)
+    if apply:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError as e:
+            return {"pinned": False, "reason": str(e)}
+    return {"pinned": bool(apply), "cpus": len(cpus), "first_cpu": min(cpus), "how": how}
+
+
 def shard_slice(n, rank, world):
     """Contiguous, balanced slice of n frames for `rank` (clips / videos are never split)."""
     base, rem = divmod(n, world)
@@ -58,16 +138,35 @@ def gather_results(local, rank, world, dst=0):
     pickled: fine for a few scalars, not for detections -- at 8 x 9k frames/s that would be 6 GB/s of pickling on rank 0)."""
     if world == 1 or not dist.is_initialized():
         return [local]
-    if not torch.is_tensor(local):
+    nccl = dist.get_backend() == "nccl"
+    ctl_dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    # Header first: every rank says WHAT it holds (tensor or object, rank, trailing shape, dtype, leading size), so all ranks
+    # take the same collective sequence and a mismatch raises on EVERY rank instead of hanging one side in a different collective.
+    is_t = torch.is_tensor(local) and local.dim() >= 1            # (a 0-dim tensor travels as an object)
+    DT = [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.int32, torch.int64, torch.uint8, torch.int8, torch.bool, torch.int16]
+    hdr = torch.zeros(12, dtype=torch.int64, device=ctl_dev)
+    if is_t:
+        if local.dim() > 8 or local.dtype not in DT:
+            raise ValueError("gather_results: unsupported tensor (dim %d, %s)" % (local.dim(), local.dtype))
+        hdr[0], hdr[1], hdr[2], hdr[3] = 1, local.dim(), DT.index(local.dtype), local.shape[0]
+        for i, d in enumerate(local.shape[1:]):
+            hdr[4 + i] = d
+    hdrs = [torch.zeros_like(hdr) for _ in range(world)]
+    dist.all_gather(hdrs, hdr)
+    hdrs = [h.cpu().tolist() for h in hdrs]
+    kinds = {h[0] for h in hdrs}
+    if len(kinds) != 1:
+        raise ValueError("gather_results: ranks disagree on what they gather (tensor on ranks %r, object on the others); pass an "
+                         "empty tensor of the right trailing shape for an empty shard" % [r for r, h in enumerate(hdrs) if h[0]])
+    if not is_t:
         out = [None] * world if rank == dst else None
         dist.gather_object(local, out, dst=dst)
         return out
-    nccl = dist.get_backend() == "nccl"
-    work = local if (nccl or not local.is_cuda) else local.cpu()
-    n = torch.tensor([work.shape[0]], dtype=torch.int64, device=work.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(t.item()) for t in sizes]
+    if any(h[1:3] != hdrs[0][1:3] or h[4:] != hdrs[0][4:] for h in hdrs):
+        raise ValueError("gather_results: trailing shape / dtype differ across ranks: %r" % [(h[1], h[2], h[4:4 + max(0, h[1] - 1)]) for h in hdrs])
+    # payload: on the data plane -- RCCL wants device tensors (a CPU tensor moves to the current device), gloo host tensors
+    work = local.to(ctl_dev) if (nccl != local.is_cuda) else local
+    sizes = [int(h[3]) for h in hdrs]
     nmax = max(sizes)
     if work.shape[0] < nmax:
         pad = torch.zeros((nmax - work.shape[0],) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)

@@ -149,6 +149,14 @@ class NetEngine(object):
         res = {"arm_loc": arm_loc, "odm_loc": odm_loc, "conf": conf, "offsets": offsets, "loc_maps": loc_maps}
         return res
 
+    def check(self):
+        """tdrn_net_check: raises TdrnError(TDRN_E_DEVICE) when a forward enqueued since the last check reported a device-side
+        hand-off failure (bounded poll ran out).  Does not synchronise: call it behind the synchronisation that ends the
+        forward (or the hipGraph replay) in question."""
+        detail = C.c_uint(0)
+        rc = self.lib.tdrn_net_check(self.handle, C.byref(detail))
+        check(rc, "device status 0x%x (1: chained split of conv3x3_pp, 2: chain launch)" % detail.value)
+
     # ---- debug / test access to internal activations ------------------------------------------
     def tensor_infos(self):
         out = []
@@ -156,6 +164,21 @@ class NetEngine(object):
             lab, c, h, w = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
             check(self.lib.tdrn_net_tensor_info(self.handle, i, C.byref(lab), C.byref(c), C.byref(h), C.byref(w)))
             out.append((lab.value.decode(), c.value, h.value, w.value))   # '' = not materialised (fused away)
+        return out
+
+    def op_infos(self):
+        """The plan's ops (tdrn_net_op_info) as dicts; tensor fields are indices into tensor_infos()."""
+        out = []
+        for i in range(self.lib.tdrn_net_op_count(self.handle)):
+            oi = _lib.OpInfo()
+            check(self.lib.tdrn_net_op_info(self.handle, i, C.byref(oi)))
+            d = {f[0]: getattr(oi, f[0]) for f in _lib.OpInfo._fields_}
+            d["in"] = d.pop("in_")
+            d["kind"] = _lib.OP_KINDS[d["kind"]]
+            d["off_c0"] = list(d["off_c0"])
+            for k in ("w", "b", "bn", "w2", "b2"):
+                d[k] = d[k].decode()
+            out.append(d)
         return out
 
     def read_tensor(self, index, batch):

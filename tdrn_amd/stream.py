@@ -10,20 +10,31 @@ Three queues, chained by events, `slots` (>= 3) buffers used cyclically:
     caller's stream:  hipGraph[slot] = tdrn_preprocess -> net (~60 launches on 4 lanes) -> Detect      (waits for its H2D)
     copy-out stream:  D2H of batch k's detections               (waits for step k; step k + slots waits for it)
 Measured (bench.py `stream`, profiles/r03_experiments.md): 0.97 of the resident rate, given copy streams that do not share a
-hardware queue with a busy lane (see _pick_streams: chosen by a 0.3-s calibration at construction).  What did NOT work: the D2H on the
+hardware queue with a busy lane (see _pick_streams: chosen by a calibration at construction -- 16 stream pairs x 12 pipeline
+steps + the four best x 32: ~320 steps on whatever the slots' buffers hold, ~1 s at batch 32; `calibrate=False` skips it).  What did NOT work: the D2H on the
 step's own stream (a 2.7-MB device-to-pinned copy there is a blit kernel that queues behind the step and costs 0.54 ms:
 0.85 of resident -- that alone was the whole shortfall of the first versions); the H2D as a node of the step's graph (the
 executor ran it ~2.4 ms into the step, in series with Detect: 0.86-0.91); copying only one batch ahead (the copy then has
 to start and finish inside one step).
 Protocol: batches 0 and 1 go into pinned_in(0), pinned_in(1), then prime(); before every run() -- which launches the
 oldest batch not yet run -- the producer writes the batch TWO ahead of it into pinned_in(next_in()); result(slot) is
-that run's output.
+that run's output.  run() returns the slot as a TICKET (an int that also carries the step number): a consumer that lags
+by `slots` or more steps and hands a stale ticket to result() gets a RuntimeError instead of a newer batch's (or a
+half-overwritten) result.
 """
 import torch
 
 from .data import base_transform
 
 AHEAD = 2        # batches copied in ahead of the one being computed
+
+
+class Ticket(int):
+    """the slot a run() used (an int, usable as before) + the pipeline step it belongs to"""
+    def __new__(cls, slot, step):
+        t = int.__new__(cls, slot)
+        t.step = step
+        return t
 
 
 class FrameStream(object):
@@ -57,7 +68,9 @@ class FrameStream(object):
         self.graphs, self.dev_out = [], []
         for s in range(slots):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # one private pool for all slots: the slots' steps run one after another on the caller's stream, so their
+            # intermediates may share memory (each slot's OUTPUT stays live and is never aliased)
+            with torch.cuda.graph(g, pool=self.graphs[0].pool() if self.graphs else None):
                 out = one_step(self.dev_in[s])
             self.graphs.append(g)
             self.dev_out.append(out)
@@ -70,6 +83,7 @@ class FrameStream(object):
         for e in self.ev_in + self.ev_step + self.ev_out:
             e.record(cur)
         self._k = 0
+        self._step_of = [-1] * slots                                   # the pipeline step whose result a slot holds (or will hold)
         self.calibration = None
         if calibrate:
             self._pick_streams()
@@ -130,6 +144,7 @@ class FrameStream(object):
         `frames`) go to the device."""
         torch.cuda.synchronize(self.dev)
         self._k = 0
+        self._step_of = [-1] * self.slots
         for s in range(AHEAD):
             if frames is not None:
                 self.host_in[s].copy_(frames[s])
@@ -148,13 +163,20 @@ class FrameStream(object):
             self._out_stream.wait_event(self.ev_step[s])
             self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
             self.ev_out[s].record(self._out_stream)
+        self._step_of[s] = self._k
         self._k += 1
-        return s
+        return Ticket(s, self._k - 1)
 
     def result(self, slot):
-        """Detections of the batch last run in `slot`, on the host (blocks until they have arrived)."""
-        self.ev_out[slot].synchronize()
-        return self.host_out[slot]
+        """Detections of the batch last run in `slot`, on the host (blocks until they have arrived).  Given the Ticket run()
+        returned, raises if the slot has been re-issued since (the consumer lagged by `slots` or more steps: the buffer holds,
+        or is being overwritten with, a newer batch); a plain int asks for whatever the slot holds."""
+        step = getattr(slot, "step", None)
+        if step is not None and self._step_of[int(slot)] != step:
+            raise RuntimeError("FrameStream.result: slot %d was re-issued for step %d; the result of step %d is gone (read results "
+                               "within %d steps, or use more slots)" % (int(slot), self._step_of[int(slot)], step, self.slots - 1))
+        self.ev_out[int(slot)].synchronize()
+        return self.host_out[int(slot)]
 
     def drain(self):
         torch.cuda.synchronize(self.dev)

@@ -78,3 +78,90 @@ def test_shard_helpers_partition_exactly():
             assert rr == list(range(n))
             sizes = [len(range(n)[tdist.shard_slice(n, r, world)]) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_mismatch(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init(backend="gloo")
+    res = []
+    # (1) one rank passes a tensor, the other None (an "empty shard"): both must RAISE, not hang in different collectives
+    try:
+        tdist.gather_results(torch.zeros(2, 3) if rank == 0 else None, rank, world)
+        res.append("no error")
+    except ValueError as e:
+        res.append("raised" if "disagree" in str(e) else str(e))
+    # (2) trailing shapes differ: raises on every rank
+    try:
+        tdist.gather_results(torch.zeros(2, 3 + rank), rank, world)
+        res.append("no error")
+    except ValueError as e:
+        res.append("raised" if "trailing shape" in str(e) else str(e))
+    # (3) the right way to gather an empty shard: an empty tensor of the right trailing shape; a 0-dim tensor travels as an object
+    got = tdist.gather_results(torch.ones(2, 3) if rank == 0 else torch.zeros(0, 3), rank, world)
+    if rank == 0:
+        res.append([tuple(g.shape) for g in got])
+    sc = tdist.gather_results(torch.tensor(float(rank)), rank, world)
+    if rank == 0:
+        res.append([float(v) for v in sc])
+    tdist.barrier()
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_gather_results_mismatch_raises_on_every_rank():
+    """the collective sequence must not depend on each rank's local Python type."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][:2] == ["raised", "raised"] and got[1][:2] == ["raised", "raised"]
+    assert got[0][2] == [(2, 3), (0, 3)] and got[0][3] == [0.0, 1.0]
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """gpus: [(bdf, vendor, class, numa_node)], nodes: {node: cpulist}"""
+    for bdf, vendor, cls, node in gpus:
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        (d / "numa_node").write_text("%d\n" % node)
+    for node, cl in nodes.items():
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+
+
+def test_rank_pinning_reads_the_gpus_numa_node_from_sysfs(tmp_path, monkeypatch):
+    """bench.py pins every rank to the CPUs of its GPU's NUMA node before the first GPU call (sysfs only)."""
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    lo, hi = allowed[:half], allowed[half:] or allowed[:half]
+    fmt = lambda cpus: ",".join(str(c) for c in cpus)
+    _fake_sysfs(tmp_path, [("0000:05:00.0", "0x1002", "0x120000", 0), ("0000:15:00.0", "0x8086", "0x030000", 0),
+                           ("0000:85:00.0", "0x1002", "0x120000", 1), ("0000:95:00.0", "0x1002", "0x038000", -1)], {0: fmt(lo), 1: fmt(hi)})
+    assert tdist.gpu_numa_nodes(str(tmp_path)) == [("0000:05:00.0", 0), ("0000:85:00.0", 1), ("0000:95:00.0", -1)]
+    d0 = tdist.pin_to_gpu_numa_node(0, 4, str(tmp_path), apply=False)
+    d1 = tdist.pin_to_gpu_numa_node(1, 4, str(tmp_path), apply=False)
+    assert d0["cpus"] == len(lo) and d0["first_cpu"] == lo[0] and "numa node 0" in d0["how"]
+    assert d1["cpus"] == len(hi) and d1["first_cpu"] == hi[0] and "numa node 1" in d1["how"]
+    d2 = tdist.pin_to_gpu_numa_node(2, 4, str(tmp_path), apply=False)          # no node reported: an even split
+    assert "even split" in d2["how"] and d2["cpus"] >= 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")                           # an index remap is followed
+    assert "numa node 1" in tdist.pin_to_gpu_numa_node(0, 2, str(tmp_path), apply=False)["how"]
+    # applying it really narrows the mask (and is undone for the rest of the test session)
+    before = os.sched_getaffinity(0)
+    try:
+        monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+        d = tdist.pin_to_gpu_numa_node(0, 4, str(tmp_path), apply=True)
+        assert d["pinned"] and os.sched_getaffinity(0) == set(lo)
+    finally:
+        os.sched_setaffinity(0, before)

@@ -775,3 +775,12 @@ def test_frame_stream_equals_unstreamed():
     assert (results[0][..., 0] > 0).any()                  # (not vacuous: there are detections)
     with pytest.raises(ValueError):
         FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=2)
+    # a consumer that lags by `slots` steps gets an error, not a newer batch's detections
+    fs.prime(feeds[:2])
+    old = fs.run()
+    for _ in range(slots):
+        last = fs.run()
+    with pytest.raises(RuntimeError):
+        fs.result(old)
+    assert fs.result(last) is not None and int(last) == int(old)
+    fs.drain()
