@@ -641,18 +641,27 @@ struct tdrn_net {
             src[3] = vgg_extras(fc7);
         }
         const int nc3 = 3 * cfg.num_classes;
-        for (int s = 0; s < 4; ++s) {
-            const std::string ss = std::to_string(s);
-            if (cfg.deform) {
+        if (cfg.deform) {
+            // all four levels' offsets first, then the four deformable heads back to back: consecutive OP_DEFORM ops run as ONE
+            // launch (the gather kernel is latency-bound per workgroup -- 72 dependent K steps with 8 groups -- so four launches
+            // cost four times the one: 4 x 230-330 us -> 330 us at config #5's batch, profiles/r04_cfg5)
+            int ot[4];
+            for (int s = 0; s < 4; ++s) {
+                const std::string ss = std::to_string(s);
                 const int rl = ref_loc_in(s, fm[s], fm[s]);
-                const int ot = offset_conv(s, fm[s], fm[s], "offset." + ss, "", true, 8 * 18, 0, -1, rl);
-                offsets_out(s, ot, 8 * 18);
-                deform_heads(src[s], ot, s, 8, "arm_loc." + ss, "arm_conf." + ss, "", "", 0, OUT_ARM_LOC);
-            } else {
-                conv(src[s], "arm_loc." + ss, true, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
-                conv(src[s], "arm_conf." + ss, true, "", nc3, 3, 1, 1, 1, 0, -1, OUT_CONF, s);
-                loc_maps_out(s);
+                ot[s] = offset_conv(s, fm[s], fm[s], "offset." + ss, "", true, 8 * 18, 0, -1, rl);
+                offsets_out(s, ot[s], 8 * 18);
             }
+            for (int s = 0; s < 4; ++s) {
+                const std::string ss = std::to_string(s);
+                deform_heads(src[s], ot[s], s, 8, "arm_loc." + ss, "arm_conf." + ss, "", "", 0, OUT_ARM_LOC);
+            }
+        }
+        for (int s = 0; s < 4 && !cfg.deform; ++s) {
+            const std::string ss = std::to_string(s);
+            conv(src[s], "arm_loc." + ss, true, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
+            conv(src[s], "arm_conf." + ss, true, "", nc3, 3, 1, 1, 1, 0, -1, OUT_CONF, s);
+            loc_maps_out(s);
         }
         if (cfg.test_phase) softmax_op();
         return TDRN_OK;

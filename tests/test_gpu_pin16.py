@@ -9,10 +9,15 @@ conv3x3_patch, ygemm_k256, deform_sample).  Three kinds of checks, all through t
       materialised input is read back (tdrn_net_read_tensor), the stage is recomputed on the CPU in fp64 with the
       16-bit-rounded BN-folded weights (model/networks.py:136-163 arithmetic, folded as net.hip does), and every output
       element must satisfy
-            |got - ref| <= ulp16(|ref| + c S) + c S,     S = sum |x| |w| (+ |bias| + |residual|),  c = 2e-6
+            |got - ref| <= ulp16(|ref| + c S) + c S,     S = sum |x| |w| (+ |bias| + |residual|),  c = 2e-6 (bf16) / 4e-5 (fp16)
       i.e. one rounding of the output to the 16-bit type plus fp32 accumulation noise -- a wrong tile, a dropped tap or
       a stale LDS row is O(|ref|), four orders of magnitude above that.  Kernel bugs and accumulated drift are thereby
-      separable: drift lives in the INPUT, which the reference convolution shares;
+      separable: drift lives in the INPUT, which the reference convolution shares.  c is per type: the bf16 matrix-core
+      path behaves as exact products + fp32 accumulation (every stage lands within HALF an output ulp + 2e-6 S: measured
+      worst error / tolerance 0.50); v_mfma_f32_32x32x16_f16 does not -- its 16-term dot products lose low bits of the
+      22-bit fp16 products (measured on gfx950, identically in conv_igemm, conv3x3_patch and conv3x3_pp: up to 2e-5 S, visible
+      only on outputs that cancel to |y| << S, e.g. one cout of conv2_1 whose outputs hover at 0.003 under S = 29; fp16
+      subnormals are NOT flushed: a flushed reference is worse), so c(fp16) = 4e-5;
   (c) the transform-then-sample deformable heads: ygemm_k256's Y against an fp64 GEMM of its device input with the
       rounded per-tap weights (same bound), and deform_sample's output against a blend of THE DEVICE'S OWN Y rows with
       bilinear weights recomputed from the device's own fp32 offsets by the reference's rule
@@ -29,7 +34,7 @@ from tdrn_amd.utils import synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 torch.set_num_threads(min(16, torch.get_num_threads()))      # (the fp64 reference convolutions: the GPU hosts' 256 threads oversubscribe)
-C_ACC = 2e-6            # fp32 accumulation noise, relative to S = sum |x||w|
+C_ACC = {"bf16": 2e-6, "fp16": 4e-5}     # accumulation noise relative to S = sum |x||w| (module docstring)
 TORCH16 = {"bf16": torch.bfloat16, "fp16": torch.float16}
 UNIT = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}     # unit roundoff of the 16-bit types
 
@@ -74,9 +79,13 @@ def _fold(sd, op):
     return wf, shift.float()
 
 
+def _add(a, b):
+    return b if a is None else (a if b is None else a + b)
+
+
 def _assert_stage(name, got, ref, S, dtype, out16=True, extra=None, report=None):
     got, ref, S = got.double(), ref.double(), S.double()
-    tol = C_ACC * S
+    tol = C_ACC[dtype] * S
     if extra is not None:
         tol = tol + extra
     if out16:
@@ -157,7 +166,7 @@ def check_stages(net, sd, x, dtype, images, skip_first_input=False):
                 y = F.conv2d(xin, w16, bf.double(), **kw)
                 S = F.conv2d(xin.abs(), w16.abs(), bf.double().abs(), **kw)
                 if op["fused_first"]:
-                    extra = 2 * u * S
+                    extra = _add(extra, 2 * u * S)
                 if op["res"] >= 0:
                     r = tensor(op["res"])[b:b + 1].double()
                     y, S = y + r, S + r.abs()
