@@ -228,6 +228,10 @@ typedef struct {
 #define TDRN_PLAN_NO_CONV_PP    32  /* conv3x3_pp.hip's layers stay on the loader/consumer kernel conv3x3_patch.hip                */
 #define TDRN_PLAN_NO_PP_SK      64  /* conv3x3_pp.hip runs whole items only (no chained split)                                     */
 #define TDRN_PLAN_NO_CONV_PATCH 128 /* neither 3x3 direct-conv kernel: every conv on the generic implicit GEMM (conv_igemm.hip)    */
+#define TDRN_PLAN_DWPW          512 /* MobileNet trunks: eight conv_dw blocks as ONE launch each (dwpw.hip dwpw_kernel: the depthwise output stays in
+                                       LDS; bit-identical; measured SLOWER than the two launches -- the depthwise conv on the vector ALU
+                                       beside 128 live accumulators -- hence opt-in)                                                    */
+#define TDRN_PLAN_NO_PW1X1      1024 /* the wide 1x1 convs stay on conv_igemm.hip instead of dwpw.hip's persistent GEMM (pw1x1_kernel)     */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 
@@ -335,6 +339,8 @@ typedef struct {
     int n_branches, k2, pad2, off_c0[2]; /* deformable heads: 3x3 (+ 5x5) branch, first offset channel of each branch          */
     int y_tap_major;   /* deformable heads with y >= 0: 1 = Y is [tap][B*H*W][80], 0 = [B*H*W][y channels] (column of tap t: (t/3)*256 + (t%3)*80) */
     int fused_first;   /* conv: 1 = this launch also computes the first conv (its `in` is then not materialised)               */
+    int fused_dw;      /* depthwise: 1 = this launch also computes the pointwise conv behind it (dwpw.hip: its `out` is not materialised
+                          and the next op, that conv, is not a launch of its own); conv: 1 = computed by the depthwise op in front   */
     char w[48], b[48], bn[48], w2[48], b2[48];  /* state_dict prefixes ('' = none): weight / bias owner / BatchNorm; second source (merged 5x5+3x3 heads; offset2;
                           deformable heads: w = 3x3 loc, b = 3x3 conf, w2 = 5x5 loc, b2 = 5x5 conf)                             */
 } tdrn_op_info;

@@ -28,7 +28,7 @@ class NetConfig(C.Structure):
 
 
 PLAN_NO_FUSE_FIRST, PLAN_NO_LATE_SIDE, PLAN_ONE_STREAM, PLAN_NO_DEFORM_TS, PLAN_CHAIN = 1, 2, 4, 8, 16      # tdrn_hip.h TDRN_PLAN_*
-PLAN_NO_CONV_PP, PLAN_NO_PP_SK, PLAN_NO_CONV_PATCH, PLAN_FAULT_HANDOFF = 32, 64, 128, 256
+PLAN_NO_CONV_PP, PLAN_NO_PP_SK, PLAN_NO_CONV_PATCH, PLAN_FAULT_HANDOFF, PLAN_DWPW, PLAN_NO_PW1X1 = 32, 64, 128, 256, 512, 1024
 E_DEVICE = -8
 
 
@@ -49,7 +49,7 @@ class OpInfo(C.Structure):
                 ("y", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int), ("relu", C.c_int),
                 ("ceil_mode", C.c_int), ("splitk", C.c_int), ("groups", C.c_int), ("out_kind", C.c_int), ("level", C.c_int),
                 ("n_branches", C.c_int), ("k2", C.c_int), ("pad2", C.c_int), ("off_c0", C.c_int * 2), ("y_tap_major", C.c_int),
-                ("fused_first", C.c_int), ("w", C.c_char * 48), ("b", C.c_char * 48), ("bn", C.c_char * 48), ("w2", C.c_char * 48),
+                ("fused_first", C.c_int), ("fused_dw", C.c_int), ("w", C.c_char * 48), ("b", C.c_char * 48), ("bn", C.c_char * 48), ("w2", C.c_char * 48),
                 ("b2", C.c_char * 48)]
 
 

@@ -622,6 +622,10 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     if (p.splits == 1 && use_patch && patch_conv_supported(a) && a.H * a.W >= use_patch * 400)
         return launch_conv3x3_patch(a, nullptr, s);
     if (a.fuse_x) return TDRN_E_UNSUPPORTED;             // only the patch kernel computes the first conv itself
+    if (p.splits == 1 && pw1x1_supported(a)) {           // wide pointwise layers: dwpw.hip's persistent GEMM (same bits)
+        const int rc1 = launch_pw1x1(a, s);
+        if (rc1 != TDRN_E_UNSUPPORTED) return rc1;       // (it declines launches too small to fill the chip)
+    }
     int rc = TDRN_E_ARG;
     switch (a.dtype) {
         case TDRN_F32: rc = launch_dt<float>(p, a.phases, s); break;

@@ -43,7 +43,7 @@ struct ConvArgs {
     void *sk_ws = nullptr;          // conv3x3_pp.hip: scratch of conv_pp_sk_bytes() for the chained split (one launch at a time), or null
     bool sk_flags_zero = false;     // the first 1024 bytes of sk_ws are zero on entry (every launch leaves them zero): no memset node
     // kernel-choice switches of this launch (tdrn_net_config.plan_flags TDRN_PLAN_NO_CONV_PP / _NO_PP_SK / _NO_CONV_PATCH):
-    // bit 0: not conv3x3_pp.hip, bit 1: no chained split, bit 2: neither 3x3 direct-conv kernel.  Same output bits either way.
+    // bit 0: not conv3x3_pp.hip, bit 1: no chained split, bit 2: neither 3x3 direct-conv kernel, bit 3: not pw1x1 (dwpw.hip).  Same output bits either way.
     int kdisable = 0;
     // host-visible status words (pinned, device-mapped; tdrn_net_check): [0] <- 1 when a chained-split poll runs out,
     // [1] <- 1 when a poll of the chain launch does.  Null: a timed-out poll is not reported (dev harness only).
@@ -94,6 +94,21 @@ int launch_l2norm(const void *in, const float *w, void *out, long long pixels, i
 // depthwise 3x3, pad 1, stride 1|2, folded BN + ReLU, NHWC DT.  w: fp32 [9][Cpad], bias [Cpad]
 int launch_dwconv3(const void *in, const float *w, const float *bias, void *out, int B, int H, int W,
                    int C, int stride, int relu, int dtype, hipStream_t s);
+// conv_dw block fused (dwpw.hip): depthwise 3x3 (stride 1, pad 1, fp32 weights [9][Cin] + bias [Cin], ReLU) -> pointwise 1x1
+// (DT weights [Npad][Cin], fp32 bias [Npad], ReLU) in one launch; the depthwise output stays in LDS.  16-bit types only.
+struct DwPwArgs {
+    const void *in = nullptr, *w = nullptr;
+    const float *wdw = nullptr, *bdw = nullptr, *bias = nullptr;   // (bdw must lie behind wdw in the same allocation: the weight blob)
+    void *out = nullptr;
+    int B = 0, H = 0, W = 0, Cin = 0, Cout = 0, Npad = 0, Cs = 0;  // Cs: channel stride of the output tensor
+    int stride = 1, relu_dw = 1, relu = 1, dtype = TDRN_BF16;
+};
+int dwpw_enabled();                              // TDRN_DWPW (default 1)
+int dwpw_supported(const DwPwArgs &a);           // 0 = no, else the tile mode
+int launch_dwpw(const DwPwArgs &a, hipStream_t s);
+// wide 1x1 convs as a persistent 256 x 256-item GEMM (dwpw.hip pw1x1_kernel); launch_conv hands them over (TDRN_PW1X1=0 / kdisable bit 3: off)
+int pw1x1_supported(const ConvArgs &a);
+int launch_pw1x1(const ConvArgs &a, hipStream_t s);
 // softmax over rows of (R, C) fp32, in place allowed
 int launch_softmax_rows(const float *in, float *out, long long R, int C, hipStream_t s);
 // 1x1 "offset" convs on the 12-channel ARM loc map: loc fp32 (pixel stride loc_ps, batch stride

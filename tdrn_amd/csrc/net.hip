@@ -63,6 +63,7 @@ struct Op {
     int splitk = 1;                                        // conv: K slices, fixed per layer at plan time
     bool chain_tag = false;                                // conv: candidate for the one-launch chain of small top-of-pyramid layers
     int chain = -1;                                        // ... its stage index in that launch (conv_igemm.hip conv_chain_kernel), or -1
+    int fused_dw = 0;                                      // depthwise op: its launch also computes the next op, the pointwise conv (dwpw.hip); that conv: 1 = computed there
     size_t chain_partial = 0;                              // ... its split-K slab inside the chain's slab region (bytes per sample)
 };
 
@@ -129,8 +130,8 @@ void put_status(unsigned *w) { if (w) { std::lock_guard<std::mutex> g(mu); statu
 }  // namespace pool
 
 const char *kStatNames[] = {"conv_igemm_mfma", "first_conv", "maxpool2x2", "l2norm", "dwconv3x3", "offset_conv1x1",
-                            "deform_gemm_mfma", "softmax21", "layout", "conv3x3_patch_mfma"};
-enum { ST_CONV, ST_FIRST, ST_POOL, ST_L2, ST_DW, ST_OFFSET, ST_DEFORM, ST_SOFTMAX, ST_LAYOUT, ST_CONV3, ST_COUNT };
+                            "deform_gemm_mfma", "softmax21", "layout", "conv3x3_patch_mfma", "dwpw_mfma"};
+enum { ST_CONV, ST_FIRST, ST_POOL, ST_L2, ST_DW, ST_OFFSET, ST_DEFORM, ST_SOFTMAX, ST_LAYOUT, ST_CONV3, ST_DWPW, ST_COUNT };
 
 }  // namespace
 }  // namespace tdrn
@@ -671,7 +672,7 @@ struct tdrn_net {
     {
         es = dtype_bytes(cfg.dtype);
         kdisable = ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PP) ? 1 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PP_SK) ? 2 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
@@ -828,6 +829,30 @@ struct tdrn_net {
                 ws_per_sample += lane_bytes[l];
             }
         }
+        // OPT-IN (TDRN_PLAN_DWPW; it measured slower than the two launches, dwpw.hip): conv_dw blocks as ONE launch:
+        // a depthwise op directly followed by its pointwise conv, which is the only
+        // reader of the depthwise output; decided from the geometry (the batch-dependent 4-GiB limit is re-checked per forward,
+        // which then falls back to the two launches: the depthwise tensor keeps its place in the workspace)
+        if (cfg.dtype != TDRN_F32 && ((cfg.plan_flags & TDRN_PLAN_DWPW) || dwpw_enabled() > 1))
+            for (size_t i = 0; i + 1 < ops.size(); ++i) {
+                Op &d = ops[i];
+                Op &c = ops[i + 1];
+                if (d.kind != OP_DW || c.kind != OP_CONV || c.in != d.out || c.k != 1 || c.stride != 1 || c.pad != 0 || c.phases != 1 || c.res >= 0 ||
+                    c.out_kind != OUT_TENSOR || c.splitk != 1 || c.lane != d.lane || c.pool_t >= 0 || c.chain >= 0) continue;
+                int readers = 0;
+                for (const Op &o : ops) readers += (o.in == d.out) + (o.res == d.out);
+                if (readers != 1) continue;
+                const Tensor &ti = tensors[d.in];
+                DwPwArgs a;
+                a.B = 1; a.H = ti.H; a.W = ti.W; a.Cin = c.Cin; a.Cout = c.Cout; a.Npad = c.Npad; a.Cs = tensors[c.out].Cpad;
+                a.stride = d.stride; a.dtype = cfg.dtype;
+                if (ti.Cpad != c.Cin || !dwpw_supported(a)) continue;
+                d.fused_dw = 1; c.fused_dw = 1;
+                d.stat = ST_DWPW;
+                d.flops += c.flops;
+                d.bytes = (double)ti.H * ti.W * ti.Cpad * es + (double)ti.H * ti.W * tensors[c.out].Cpad * es;
+                c.flops = 0; c.bytes = 0;
+            }
         // conv3x3_pp.hip's chained split needs a slab per workgroup; only launches on the main lane use it (one at a time)
         // Batch-independent tail of the workspace: [256 B: the chain launch's counters][1 KiB: the chained split's flag words]
         // [its slabs]; the first 1280 bytes are zeroed once per forward.
@@ -1206,6 +1231,7 @@ struct tdrn_net {
             if (d.kind == OP_DEFORM && d.y_t >= 0 && !ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) ts_tap_major = 0;
         int ts_cs[4] = {0, 0, 0, 0}, ts_op[4] = {-1, -1, -1, -1};
         int n_dargs = 0;
+        bool dwpw_done = false;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &o = ops[oi];
             bool skip = false;
@@ -1213,6 +1239,7 @@ struct tdrn_net {
             if (o.kind == OP_LOC_OUT && !io->loc_maps[o.scale]) skip = true;
             if (o.kind == OP_FIRST && fuse_first >= 0) skip = true;            // computed inside the next conv's patch loader
             if (o.kind == OP_CONV && o.chain > 0) skip = true;                 // computed by the chain launch at its first member's place
+            if (o.kind == OP_CONV && o.fused_dw && dwpw_done) { skip = true; dwpw_done = false; }   // computed by the depthwise op's launch
             if (skip) continue;
             const int lane = lanes ? o.lane : 0;
             hipStream_t s = lane == 0 ? s0 : side[lane - 1];
@@ -1318,6 +1345,21 @@ struct tdrn_net {
                 }
                 case OP_DW: {
                     const Tensor &ti = tensors[o.in];
+                    if (o.fused_dw) {
+                        const Op &c = ops[oi + 1];
+                        DwPwArgs a;
+                        a.in = tptr(ws, o.in, B); a.w = wb + c.w_off; a.wdw = (const float *)(wb + o.w_off); a.bdw = (const float *)(wb + o.b_off);
+                        a.bias = (const float *)(wb + c.b_off); a.out = tptr(ws, c.out, B);
+                        a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = c.Cin; a.Cout = c.Cout; a.Npad = c.Npad; a.Cs = tensors[c.out].Cpad;
+                        a.stride = o.stride; a.relu_dw = o.relu; a.relu = c.relu; a.dtype = cfg.dtype;
+                        if (dwpw_supported(a)) {
+                            rc = launch_dwpw(a, s);
+                            dwpw_done = true;
+                            // (the pointwise op's output tensor is produced HERE: its cross-lane event is recorded below through `o2`)
+                            if (rc == TDRN_OK && lanes && c.out >= 0 && tensor_shared[c.out]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[c.out], s));
+                            break;
+                        }
+                    }
                     rc = launch_dwconv3(tptr(ws, o.in, B), (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
                                         tptr(ws, o.out, B), B, ti.H, ti.W, ti.Cpad, o.stride, o.relu, cfg.dtype, s);
                     break;
@@ -1461,7 +1503,7 @@ struct tdrn_net {
         }
         bool prev_deform = false;
         for (const Op &o : ops) {
-            if (!(o.kind == OP_DEFORM && prev_deform) && !(o.kind == OP_CONV && o.chain > 0)) stats[o.stat].launches += 1;
+            if (!(o.kind == OP_DEFORM && prev_deform) && !(o.kind == OP_CONV && o.chain > 0) && !(o.kind == OP_CONV && o.fused_dw)) stats[o.stat].launches += 1;
             prev_deform = o.kind == OP_DEFORM;
             stats[o.stat].flops += o.flops * last_batch;
             stats[o.stat].bytes += o.bytes * last_batch;
@@ -1609,6 +1651,7 @@ int tdrn_net_op_info(const tdrn_net *net, int index, tdrn_op_info *out)
         out->y_tap_major = all ? 1 : 0;
     }
     out->fused_first = (index == net->fuse_first) ? 1 : 0;
+    out->fused_dw = o.fused_dw;
     auto cp = [](char *d, const std::string &v) { strncpy(d, v.c_str(), 47); };
     cp(out->w, o.w); cp(out->b, o.b); cp(out->bn, o.bn); cp(out->w2, o.w2); cp(out->b2, o.b2);
     return TDRN_OK;

@@ -705,6 +705,41 @@ def test_fused_first_conv_equals_two_launches(model, args, monkeypatch):
         assert "first_conv" not in names[0] and names[1][0] == "first_conv"
 
 
+@pytest.mark.parametrize("model,args", [("dualrefinedet_mobilenet", (320, 21, 1, True)), ("ssd4scale_mobile", (320, 21, 1024, False))])
+def test_fused_dwpw_equals_two_launches(model, args):
+    """Opt-in plan TDRN_PLAN_DWPW: eight of the MobileNet trunk's conv_dw blocks (model/networks.py:736-745) as ONE launch each
+    (dwpw.hip dwpw_kernel: the depthwise output stays in LDS; measured slower than the two launches, hence opt-in).  Same
+    depthwise FMA order, same rounding of the intermediate, same K order and bias placement as the default plan (dwconv3_strip +
+    the 1x1 GEMM): every output BIT-identical, at the build size and other frame sizes (2-D and flat tiles, ragged last tiles)
+    and at batches 1 / 3 / 8."""
+    cases = [(320, 1), (320, 3), (320, 8), (384, 2), (512, 1)] + ([(256, 3)] if model == "ssd4scale_mobile" else [])
+    for dtype in ("bf16", "fp16"):
+        fused, _ = _build(model, args)
+        fused.set_plan_flags(_lib.PLAN_DWPW)
+        fused.set_compute_dtype(dtype)
+        plain, _ = _build(model, args)
+        plain.set_compute_dtype(dtype)
+        for size, batch in cases:
+            x = torch.from_numpy(synth.synth_frames(batch, size, seed=90 + size + batch)).to(DEV)
+            a = fused(x)
+            b = plain(x)
+            for u, v in zip(a, b):
+                if torch.is_tensor(u):
+                    assert torch.equal(u, v), (model, dtype, size, batch)
+                elif u is not None:
+                    for uu, vv in zip(u, v):
+                        assert torch.equal(uu, vv), (model, dtype, size, batch)
+        names = []
+        for net in (fused, plain):                              # (not vacuous: the launch lists differ)
+            eng = net._engine
+            eng.set_profile(1)
+            eng.forward(torch.from_numpy(synth.synth_frames(1, 320, seed=3)).to(DEV))
+            torch.cuda.synchronize()
+            names.append([o["name"].split(":")[0] for o in eng.op_stats()])
+            eng.set_profile(0)
+        assert names[0].count("dwpw_mfma") == 8 and "dwpw_mfma" not in names[1] and len(names[0]) == len(names[1]) - 8
+
+
 def test_chain_launch_equals_one_launch_per_layer():
     """Opt-in plan TDRN_PLAN_CHAIN: the small top-of-pyramid layers (extras, last TCB level, its up-sampling, the lateral of the
     level below) as ONE launch -- a queue of tiles and split-K reduce ranges with per-stage completion counters

@@ -153,7 +153,16 @@ def check_stages(net, sd, x, dtype, images, skip_first_input=False):
             kw = dict(stride=op["stride"], padding=op["pad"], dilation=op["dil"])
             for b in images:
                 extra = None
-                if op["fused_first"]:
+                if op.get("fused_dw"):
+                    # computed inside the depthwise op's launch (dwpw.hip): its input is the fp64 restatement of that op on ITS
+                    # materialised input, rounded; an intermediate whose rounding falls the other way on the device (a tie
+                    # within fp32 noise) differs by one ulp16, bounded by u * S of this stage
+                    d = ops[oi - 1]
+                    wfd, bfd = _fold(sd, d)
+                    xd = tensor(d["in"])[b:b + 1].double()
+                    yd = F.conv2d(xd, wfd.double(), bfd.double(), stride=d["stride"], padding=1, groups=xd.shape[1])
+                    xin = _round16(yd.clamp(min=0) if d["relu"] else yd, dtype)
+                elif op["fused_first"]:
                     # the launch computes conv1_1 itself: its input is the fp64 restatement of that stage, rounded; where the
                     # device's rounding of an intermediate falls the other way (a tie within fp32 noise) the difference is
                     # one ulp16 of that element, bounded by u * S of this stage
@@ -165,7 +174,7 @@ def check_stages(net, sd, x, dtype, images, skip_first_input=False):
                     xin = tensor(op["in"])[b:b + 1].double()
                 y = F.conv2d(xin, w16, bf.double(), **kw)
                 S = F.conv2d(xin.abs(), w16.abs(), bf.double().abs(), **kw)
-                if op["fused_first"]:
+                if op["fused_first"] or op.get("fused_dw"):
                     extra = _add(extra, 2 * u * S)
                 if op["res"] >= 0:
                     r = tensor(op["res"])[b:b + 1].double()
@@ -198,6 +207,8 @@ def check_stages(net, sd, x, dtype, images, skip_first_input=False):
                     y = y.clamp(min=0)
                 _assert_stage(name, tensor(op["out"])[b:b + 1], y, S, dtype, report=report)
         elif kind == "depthwise":
+            if op.get("fused_dw"):
+                continue                                         # its output never leaves LDS: checked through the pointwise conv behind it
             wf, bf = _fold(sd, op)                               # (the depthwise kernel keeps its weights in fp32)
             for b in images:
                 xin = tensor(op["in"])[b:b + 1].double()
@@ -363,13 +374,19 @@ def test_every_stage_512_batch3(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_every_stage_mobilenet(dtype):
-    """The MobileNet trunk's launches (depthwise strips, 1x1 GEMMs, stride-2 first conv) from their own inputs."""
-    net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True), phase="train", dtype=dtype)
+@pytest.mark.parametrize("plan", ["two_launches", "fused"])
+def test_every_stage_mobilenet(dtype, plan):
+    """The MobileNet trunk's launches from their own inputs: the default plan (depthwise strips, 1x1 GEMMs on dwpw.hip's
+    pw1x1_kernel, stride-2 first conv: every stage strictly) and the opt-in plan TDRN_PLAN_DWPW, where eight conv_dw blocks are ONE
+    launch each (the pair is checked from the depthwise op's input; the strict pin of those blocks is the bit-identity of the two
+    plans, tests/test_gpu_net.py::test_fused_dwpw_equals_two_launches)."""
+    net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True), phase="train", dtype=dtype, flags=_lib.PLAN_DWPW if plan == "fused" else 0)
     x = torch.from_numpy(synth.synth_frames(2, 320, seed=47)).to(DEV)
     report, checked = check_stages(net, sd, x, dtype, images=(1,))
-    _print_report("mobilenet %s" % dtype, report, checked)
-    assert checked.get("depthwise", 0) == 15 and checked.get("conv", 0) >= 30 and checked.get("first_conv", 0) == 1
+    _print_report("mobilenet %s %s" % (plan, dtype), report, checked)
+    fused = sum(1 for o in net._engine.op_infos() if o["kind"] == "depthwise" and o["fused_dw"])
+    assert fused == (8 if plan == "fused" else 0)
+    assert checked.get("depthwise", 0) == 15 - fused and checked.get("conv", 0) >= 30 and checked.get("first_conv", 0) == 1
 
 
 def _outputs(net, x):
