@@ -278,6 +278,10 @@ typedef struct {
     float *offsets[4];     /* optional (B,G*18,H,W) fp32 NCHW out (arm_offset_list); or NULL */
     const float *ref_loc[4]; /* ssd4scale deform=1: (B,12,H,W) fp32 NCHW loc maps IN        */
     float *loc_maps[4];    /* ssd4scale ret_loc: (B,12,H,W) fp32 NCHW raw loc maps OUT       */
+    /* reserved[0] != NULL, ssd4scale deform=1 only: REUSE the deformable offsets the previous forward of this net computed in
+     * this workspace at this batch size instead of recomputing them from ref_loc (the reference's cached offset_list of the frames
+     * between two key frames, evaluate_trn.py:459-462: offsets are a function of the key frame's loc maps only).  ref_loc may then
+     * be NULL; TDRN_E_STATE when no such forward came before (other workspace, other batch). */
     void *reserved[4];
 } tdrn_net_io;
 

@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const char *__restri
     const bool fixed_ch = (256 % cpr) == 0;                // then i % cpr never changes for this thread
     float wt[9][P16], bs[P16];
     int ch_loaded = -1;
+    // (measured and rejected, round 4: an XCD-aware block order -- every XCD a contiguous range of output rows, so that the rows
+    // shared by vertically adjacent strips are fetched into ONE L2; FETCH_SIZE says every input row is fetched ~1.8 times -- made
+    // the large maps SLOWER (160x160: 120 -> 150 us, 40x40 x 512 ch: 67 -> 73 us) and only the 20x20 maps faster (34 -> 30 us))
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const int ch = fixed_ch ? (int)(threadIdx.x % cpr) : (int)(i % cpr);
         long long r = i / cpr;

@@ -175,6 +175,8 @@ struct tdrn_net {
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
     int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
+    const void *offs_ws = nullptr;      // ssd4scale deform: the workspace / batch whose offset tensors the last forward filled
+    int offs_batch = 0;
     int dev = -1;                       // the device the pooled handles below belong to (the one current at the first forward)
     unsigned *status = nullptr;         // host-visible status words (pinned; tdrn_net_check): [0] chained split, [1] chain launch
     int kdisable = 0, fault_handoff = 0;
@@ -1232,11 +1234,15 @@ struct tdrn_net {
         int ts_cs[4] = {0, 0, 0, 0}, ts_op[4] = {-1, -1, -1, -1};
         int n_dargs = 0;
         bool dwpw_done = false;
+        const bool reuse_offsets = cfg.deform && io->reserved[0] != nullptr;
+        if (reuse_offsets && (offs_ws != ws || offs_batch != B)) return TDRN_E_STATE;
+        if (cfg.deform && !reuse_offsets) { offs_ws = ws; offs_batch = B; }
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &o = ops[oi];
             bool skip = false;
             if (o.kind == OP_OFF_OUT && !io->offsets[o.scale]) skip = true;
             if (o.kind == OP_LOC_OUT && !io->loc_maps[o.scale]) skip = true;
+            if (reuse_offsets && (o.kind == OP_REFLOC_IN || o.kind == OP_OFFSET)) skip = true;   // (their tensors still hold the key frame's)
             if (o.kind == OP_FIRST && fuse_first >= 0) skip = true;            // computed inside the next conv's patch loader
             if (o.kind == OP_CONV && o.chain > 0) skip = true;                 // computed by the chain launch at its first member's place
             if (o.kind == OP_CONV && o.fused_dw && dwpw_done) { skip = true; dwpw_done = false; }   // computed by the depthwise op's launch

@@ -99,7 +99,7 @@ class NetEngine(object):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None):
+    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None, reuse_offsets_token=None):
         _lib.require_cuda(x, "input")
         if self.weights is None:
             raise RuntimeError("weights were never packed (load() / broadcast_weights())")
@@ -135,6 +135,15 @@ class NetEngine(object):
             offsets = [torch.empty((B, g18, f, f), dtype=torch.float32, device=dev) for f in self.fm]
             for i, t in enumerate(offsets):
                 io.offsets[i] = t.data_ptr()
+        # TRN temporal nets: the offsets computed by an earlier forward of THIS engine in the same workspace at the same batch are
+        # reused when the caller presents the token that forward handed out (tdrn_net_io.reserved[0])
+        reuse = (reuse_offsets_token is not None and reuse_offsets_token is getattr(self, "_offs_token", None)
+                 and self._offs_key == (ws.data_ptr(), B))
+        if reuse:
+            io.reserved[0] = 1
+            ref_loc = None
+        elif self.cfg.deform and ref_loc is not None:
+            self._offs_token, self._offs_key = object(), (ws.data_ptr(), B)
         if ref_loc is not None:
             for i, t in enumerate(ref_loc):
                 t = t.contiguous().float()
@@ -146,7 +155,8 @@ class NetEngine(object):
                 io.loc_maps[i] = t.data_ptr()
         check(self.lib.tdrn_net_forward(self.handle, ptr(self.weights), ptr(ws), ws.numel(), C.byref(io),
                                         _lib.current_stream(dev)), "tdrn_net_forward")
-        res = {"arm_loc": arm_loc, "odm_loc": odm_loc, "conf": conf, "offsets": offsets, "loc_maps": loc_maps}
+        res = {"arm_loc": arm_loc, "odm_loc": odm_loc, "conf": conf, "offsets": offsets, "loc_maps": loc_maps,
+               "offsets_token": getattr(self, "_offs_token", None)}
         return res
 
     def check(self):

@@ -42,9 +42,12 @@ class SSD4Scale(EngineModule):
             ref_loc = getattr(offset_list, "ref_loc", None)
             if ref_loc is None:
                 raise ValueError("deform=True needs ref_loc (or an offset_list returned by this net)")
+        # (the frames between two key frames hand back the offset_list of the key frame: its offsets are still in the engine's
+        # workspace -- the token says so -- and are not recomputed, as in evaluate_trn.py:459-462)
         r = self.engine_for(x).forward(x, want_offsets=bool(ret_off and self.deform),
                                           ref_loc=ref_loc if self.deform else None,
-                                          want_loc_maps=bool(ret_loc and not self.deform))
+                                          want_loc_maps=bool(ret_loc and not self.deform),
+                                          reuse_offsets_token=getattr(offset_list, "token", None) if (self.deform and not ret_off) else None)
         conf = r["conf"] if self.phase == 'test' else r["conf"].view(x.size(0), -1, self.num_classes)
         out = [r["arm_loc"], conf]
         if ret_loc:
@@ -52,6 +55,7 @@ class SSD4Scale(EngineModule):
         if ret_off:
             offs = _OffsetList(r["offsets"] or [])
             offs.ref_loc = list(ref_loc)
+            offs.token = r["offsets_token"]
             out.append(offs)
         return tuple(out)
 
