@@ -356,6 +356,15 @@ TDRN_API int tdrn_net_tensor_info(const tdrn_net *net, int index, const char **l
                                   int *W);
 TDRN_API int tdrn_net_read_tensor(const tdrn_net *net, const void *workspace, int batch, int index,
                                   float *out_dev, void *stream);
+/* The inverse, and a forward that starts in the middle of the plan -- analysis only (scripts/attribution.py: which stage's
+ * 16-bit rounding moves a detection): tdrn_net_write_tensor stores fp32 NCHW values (B,C,H,W) into tensor `index` of the
+ * workspace, rounded once to the net dtype; tdrn_net_forward_from runs the plan's ops [first_op, end) assuming everything the
+ * earlier ops produce (workspace tensors, and the head outputs in `io` that earlier ops wrote) is already in place.  Needs a
+ * TDRN_PLAN_ONE_STREAM plan (TDRN_E_STATE otherwise: the side lanes' event graph assumes a whole forward). */
+TDRN_API int tdrn_net_write_tensor(const tdrn_net *net, void *workspace, int batch, int index,
+                                   const float *in_dev, void *stream);
+TDRN_API int tdrn_net_forward_from(tdrn_net *net, const void *weights_dev, void *workspace,
+                                   size_t workspace_bytes, const tdrn_net_io *io, int first_op, void *stream);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,8 @@ _SIGS = {
     "tdrn_net_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tdrn_net_read_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tdrn_net_write_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tdrn_net_forward_from": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(NetIO), C.c_int, C.c_void_p]),
     "tdrn_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "tdrn_net_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int]),
     "tdrn_net_op_stats": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int]),

@@ -538,35 +538,44 @@ struct YGemmParams {
     int M, N, ycs, parts, tiles_per_part, taps;
 };
 
-template <typename DT>
-__global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
+// CT = column tiles (of 32) per wave.  CT = 1: eight waves x 32 columns (round 3, the default).  CT = 2 (round 4, TDRN_YGEMM_CT=2): FOUR waves x 64
+// columns -- 128 weight registers per wave, two workgroups of four waves per CU: every wave still reads the whole 16-KiB pixel tile
+// from LDS per tile, but there are half as many waves doing it for the same 256 columns, so the LDS reads per output halve (CT = 1:
+// 128 KiB of LDS reads per tile = 1024 cycles beside 1024 cycles of MFMA per SIMD: the two pipes were co-critical).  Same K order
+// per output element: bit-identical.
+template <typename DT, int CT>
+__global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k256_kernel(const YGemmParams p)
 {
+    constexpr int NW = 8 / CT;                           // waves per workgroup
+    constexpr int NT = NW * 64;
     constexpr int TP = 32;                               // pixels per tile
     constexpr int TBYTES = TP * 512;                     // 16 KiB
     constexpr int SROW = 512 + 16;                       // staging row: 256 columns + a 16-byte pad (bank spread)
+    constexpr int PPW = 16 / NW;                         // LDS-DMA pieces per wave and tile
     __shared__ __attribute__((aligned(16))) char smem[2 * TBYTES];
     __shared__ __attribute__((aligned(16))) char sst[TP * SROW];     // the output tile [pixel][256 columns]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
     const int cg = blockIdx.x, part = blockIdx.y;
-    const int col0 = cg * 256 + wave * 32;
-    // my 32 columns x 256 channels: fragment kk = channels [16kk + 8hh, +8) of column col0 + r32
-    u32x4 wf[16];
-    {
-        const char *wr = p.w + ((size_t)(col0 + r32) * 256 + 8 * hh) * 2;
+    const int col0 = cg * 256 + wave * (32 * CT);
+    // my 32 CT columns x 256 channels: fragment [ct][kk] = channels [16kk + 8hh, +8) of column col0 + 32 ct + r32
+    u32x4 wf[CT][16];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) wf[kk] = *(const u32x4 *)(wr + kk * 32);
+    for (int ct = 0; ct < CT; ++ct) {
+        const char *wr = p.w + ((size_t)(col0 + 32 * ct + r32) * 256 + 8 * hh) * 2;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wf[ct][kk] = *(const u32x4 *)(wr + kk * 32);
     }
     const int t0 = part * p.tiles_per_part;
     int nt = (p.M + TP - 1) / TP - t0;
     nt = nt < p.tiles_per_part ? nt : p.tiles_per_part;
     if (nt <= 0) return;
-    // staging: a tile = 32 rows x 512 B = 16 pieces of 1 KiB (2 rows each); wave w issues pieces 2w, 2w+1.
+    // staging: a tile = 32 rows x 512 B = 16 pieces of 1 KiB (2 rows each); wave w issues pieces PPW w .. PPW w + PPW - 1.
     // LDS image linear; the 16-byte chunk c of row r is stored at chunk position c ^ (r & 31) (swizzle on the SOURCE address)
     auto stage = [&](int t, int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int piece = 2 * wave + j;
+        for (int j = 0; j < PPW; ++j) {
+            const int piece = PPW * wave + j;
             const int row = 2 * piece + (lane >> 5), cpos = lane & 31;
             long long m = (long long)(t0 + t) * TP + row;
             if (m >= p.M) m = p.M - 1;                   // (rows past the end re-read the last pixel; their results are not stored)
@@ -577,48 +586,59 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
     };
     stage(0, 0);
     // 16-byte store instructions this wave issues per full tile (wave-uniform)
-    int nst_prev = 2;
+    constexpr int NSTR = 32 * 32 / NT;                   // row-major layout: 32 rows x 32 chunks / threads
+    int nst_prev = NSTR;
     if (p.taps > 0) {
         nst_prev = 0;
-        for (int it = wave; it < 18; it += 8) nst_prev += (cg * 3 + it / 6) < p.taps ? 1 : 0;
+        for (int it = wave; it < 18; it += NW) nst_prev += (cg * 3 + it / 6) < p.taps ? 1 : 0;
     }
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) {
             stage(t + 1, buf ^ 1);                       // (its last readers passed the barrier that ended tile t-1)
-            // tile t's two pieces must have landed; younger than them and free to stay in flight: the previous tile's 16-byte
-            // stores of THIS wave (nst_prev of them: two in the row-major layout -- always issued: a tile inside the partition has a
-            // live row --, 0..3 in the tap-major one, where the last slice holds fewer than three taps) and the two pieces just issued
-            switch (t == 0 ? 0 : nst_prev) {
-                case 0: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            // tile t's pieces must have landed; younger than them and free to stay in flight: the previous tile's 16-byte
+            // stores of THIS wave (nst_prev of them; always issued in the row-major layout, 0..5 in the tap-major one, where the
+            // last slice holds fewer than three taps) and the PPW pieces just issued
+            switch ((t == 0 ? 0 : nst_prev) + PPW) {
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                    // (raw: __syncthreads() would drain the piece just issued)
         asm volatile("" ::: "memory");
-        f32x16 acc;
+        f32x16 acc[CT];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
         const char *ab = smem + buf * TBYTES + r32 * 512;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const u32x4 a = *(const u32x4 *)(ab + (((2 * kk + hh) ^ r32) << 4));
-            MmaD<DT>::run(wf[kk], a, acc);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) MmaD<DT>::run(wf[ct][kk], a, acc[ct]);
         }
-        // lane = pixel r32; register e = column (e & 3) + 8 (e >> 2) + 4 hh of my 32.  The tile goes through an LDS image
+        // lane = pixel r32; register e = column (e & 3) + 8 (e >> 2) + 4 hh of a 32-column tile.  The tile goes through an LDS image
         // [pixel][256 columns] so that the stores are whole 128-byte lines (512 B per pixel row, 16 B per lane): written as
         // 8-byte pieces straight from the registers, a line of Y was assembled from eight partial writes (222 -> 167 us for
         // the four levels).  The staging stores are inline asm: in front of an LDS store it can see, hipcc drains every LDS-DMA
         // piece in flight with a vmcnt(0).
-        const unsigned sa = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)sst + (unsigned)(r32 * SROW + (wave * 32 + 4 * hh) * 2);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint2 v = make_uint2(pack2<DT>(acc[4 * g], acc[4 * g + 1]), pack2<DT>(acc[4 * g + 2], acc[4 * g + 3]));
-            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(v), "n"(16 * g) : "memory");
+        for (int ct = 0; ct < CT; ++ct) {
+            const unsigned sa = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)sst + (unsigned)(r32 * SROW + (wave * 32 * CT + 32 * ct + 4 * hh) * 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 v = make_uint2(pack2<DT>(acc[ct][4 * g], acc[ct][4 * g + 1]), pack2<DT>(acc[ct][4 * g + 2], acc[ct][4 * g + 3]));
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(v), "n"(16 * g) : "memory");
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);              // my LDS reads of tile t have returned, my staging writes are done ...
@@ -630,7 +650,7 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
             // A slice holds three whole taps (deform_y_col); a wave stores one (tap, 6-pixel group) per trip: lane = 10 * pixel +
             // chunk -> 960 contiguous bytes.
             const int px = lane / 10, k = lane - 10 * px;
-            for (int it = wave; it < 18; it += 8) {                  // three taps per slice (deform_y_col) x six 6-pixel groups
+            for (int it = wave; it < 18; it += NW) {                 // three taps per slice (deform_y_col) x six 6-pixel groups
                 const int sgi = it / 6, pg = it - sgi * 6;
                 const int tap = cg * 3 + sgi;
                 const int row = pg * 6 + px;
@@ -640,8 +660,8 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_kernel(const YGemmParams p)
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int row = (threadIdx.x >> 5) + 16 * q, ch = threadIdx.x & 31;      // 32 lanes = one pixel row of 512 B
+            for (int q = 0; q < NSTR; ++q) {
+                const int row = (threadIdx.x >> 5) + (NT / 32) * q, ch = threadIdx.x & 31;      // 32 lanes = one pixel row of 512 B
                 const long long m = (long long)(t0 + t) * TP + row;
                 if (m < p.M) *(u32x4 *)(p.y + ((size_t)m * p.ycs + cg * 256) * 2 + ch * 16) = *(const u32x4 *)(sst + row * SROW + ch * 16);
             }
@@ -678,8 +698,17 @@ int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int 
     p.parts = parts;
     p.tiles_per_part = (tiles + parts - 1) / parts;
     dim3 grid((unsigned)cgs, (unsigned)parts);
-    if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t>), grid, dim3(512), 0, s, p);
+    static int ct = -1;
+    // CT = 2 (four waves x 64 columns: half the LDS reads per output) measured 337-344 us against 332-334 us for the pair of deform
+    // launches (round 4, interleaved): the transform is not bound by its LDS reads; the round-3 shape stays the default
+    if (ct < 0) { const char *e = getenv("TDRN_YGEMM_CT"); ct = e ? atoi(e) : 1; }
+    if (ct == 1) {
+        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 1>), grid, dim3(512), 0, s, p);
+    } else {
+        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 2>), grid, dim3(256), 0, s, p);
+    }
     return hip_status(hipGetLastError());
 }
 

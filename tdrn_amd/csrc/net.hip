@@ -1091,6 +1091,7 @@ struct tdrn_net {
     // ---- forward ------------------------------------------------------------------------------
     char *tptr(void *ws, int id, int B) const { return (char *)ws + tensors[id].off * (size_t)B; }
 
+    int first_op = 0;                    // tdrn_net_forward_from: ops below this index are assumed done (analysis only)
     int forward(const void *blob, void *ws, size_t ws_bytes, const tdrn_net_io *io, hipStream_t s0)
     {
         if (!weights_ready) return TDRN_E_STATE;
@@ -1246,6 +1247,7 @@ struct tdrn_net {
             if (o.kind == OP_FIRST && fuse_first >= 0) skip = true;            // computed inside the next conv's patch loader
             if (o.kind == OP_CONV && o.chain > 0) skip = true;                 // computed by the chain launch at its first member's place
             if (o.kind == OP_CONV && o.fused_dw && dwpw_done) { skip = true; dwpw_done = false; }   // computed by the depthwise op's launch
+            if ((int)oi < first_op) skip = true;
             if (skip) continue;
             const int lane = lanes ? o.lane : 0;
             hipStream_t s = lane == 0 ? s0 : side[lane - 1];
@@ -1682,6 +1684,25 @@ int tdrn_net_read_tensor(const tdrn_net *net, const void *workspace, int batch, 
     const Tensor &t = net->tensors[index];
     return launch_nhwc_any_to_nchw_f32((const char *)workspace + t.off * (size_t)batch, t.f32 ? TDRN_F32 : net->cfg.dtype,
                                        t.Cpad, out_dev, batch, t.C, t.H * t.W, (hipStream_t)stream);
+}
+
+int tdrn_net_write_tensor(const tdrn_net *net, void *workspace, int batch, int index, const float *in_dev, void *stream)
+{
+    if (!net || !workspace || !in_dev || batch <= 0 || index < 0 || index >= (int)net->tensors.size()) return TDRN_E_ARG;
+    const Tensor &t = net->tensors[index];
+    return launch_nchw_to_nhwc(in_dev, (char *)workspace + t.off * (size_t)batch, batch, t.C, t.H * t.W, t.Cpad,
+                               t.f32 ? TDRN_F32 : net->cfg.dtype, (hipStream_t)stream);
+}
+
+int tdrn_net_forward_from(tdrn_net *net, const void *weights_dev, void *workspace, size_t workspace_bytes, const tdrn_net_io *io,
+                          int first_op, void *stream)
+{
+    if (!net || first_op < 0 || first_op > (int)net->ops.size()) return TDRN_E_ARG;
+    if (net->use_lanes) return TDRN_E_STATE;
+    net->first_op = first_op;
+    const int rc = net->forward(weights_dev, workspace, workspace_bytes, io, (hipStream_t)stream);
+    net->first_op = 0;
+    return rc;
 }
 
 int tdrn_net_profile(tdrn_net *net, int enable)

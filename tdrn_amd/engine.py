@@ -99,7 +99,12 @@ class NetEngine(object):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None, reuse_offsets_token=None):
+    def write_tensor(self, index, values):
+        """analysis only: fp32 (B,C,H,W) values -> tensor `index` of the workspace, rounded once to the net dtype"""
+        v = values.to(self.device, torch.float32).contiguous()
+        check(self.lib.tdrn_net_write_tensor(self.handle, ptr(self._ws), v.size(0), index, ptr(v), _lib.current_stream(self.device)))
+
+    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None, reuse_offsets_token=None, first_op=0):
         _lib.require_cuda(x, "input")
         if self.weights is None:
             raise RuntimeError("weights were never packed (load() / broadcast_weights())")
@@ -153,8 +158,12 @@ class NetEngine(object):
             loc_maps = [torch.empty((B, 12, f, f), dtype=torch.float32, device=dev) for f in self.fm]
             for i, t in enumerate(loc_maps):
                 io.loc_maps[i] = t.data_ptr()
-        check(self.lib.tdrn_net_forward(self.handle, ptr(self.weights), ptr(ws), ws.numel(), C.byref(io),
-                                        _lib.current_stream(dev)), "tdrn_net_forward")
+        if first_op:
+            check(self.lib.tdrn_net_forward_from(self.handle, ptr(self.weights), ptr(ws), ws.numel(), C.byref(io), int(first_op),
+                                                 _lib.current_stream(dev)), "tdrn_net_forward_from")
+        else:
+            check(self.lib.tdrn_net_forward(self.handle, ptr(self.weights), ptr(ws), ws.numel(), C.byref(io),
+                                            _lib.current_stream(dev)), "tdrn_net_forward")
         res = {"arm_loc": arm_loc, "odm_loc": odm_loc, "conf": conf, "offsets": offsets, "loc_maps": loc_maps,
                "offsets_token": getattr(self, "_offs_token", None)}
         return res
