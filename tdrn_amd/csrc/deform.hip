@@ -543,9 +543,24 @@ struct YGemmParams {
 // from LDS per tile, but there are half as many waves doing it for the same 256 columns, so the LDS reads per output halve (CT = 1:
 // 128 KiB of LDS reads per tile = 1024 cycles beside 1024 cycles of MFMA per SIMD: the two pipes were co-critical).  Same K order
 // per output element: bit-identical.
+// up to four independent problems (the pyramid levels) in ONE launch: the transforms of the small levels fill the tail of the
+// large one, and three kernel boundaries (~7 us each in the step, round 4 trace) disappear from the critical path
+struct YGemmMulti {
+    YGemmParams p[4];
+    int block_start[5];            // workgroups of problem i: [block_start[i], block_start[i+1]); inside: cg = local % cgs, part = local / cgs
+    int n;
+};
+
 template <typename DT, int CT>
-__global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k256_kernel(const YGemmParams p)
+__global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k256_kernel(const YGemmMulti mp)
 {
+    int prob = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < mp.n && (int)blockIdx.x >= mp.block_start[i]) prob = i;
+    const YGemmParams &p = mp.p[prob];
+    const int local_blk = (int)blockIdx.x - mp.block_start[prob];
+    const int ncg = p.N / 256;
     constexpr int NW = 8 / CT;                           // waves per workgroup
     constexpr int NT = NW * 64;
     constexpr int TP = 32;                               // pixels per tile
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k2
     __shared__ __attribute__((aligned(16))) char sst[TP * SROW];     // the output tile [pixel][256 columns]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
-    const int cg = blockIdx.x, part = blockIdx.y;
+    const int part = local_blk / ncg, cg = local_blk - part * ncg;
     const int col0 = cg * 256 + wave * (32 * CT);
     // my 32 CT columns x 256 channels: fragment [ct][kk] = channels [16kk + 8hh, +8) of column col0 + 32 ct + r32
     u32x4 wf[CT][16];
@@ -673,15 +688,14 @@ __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k2
 
 int ygemm_supported(int Cin, int ycols, int dtype) { return dtype != TDRN_F32 && Cin == 256 && ycols % 256 == 0; }
 
-int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s, int taps)
+static int ygemm_fill(const YGemmProblem &q, int dtype, YGemmParams &p, int &blocks)
 {
-    if (!ygemm_supported(256, N, dtype) || M <= 0 || M >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
-    YGemmParams p;
-    p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
-    p.M = (int)M; p.N = N; p.ycs = ycs; p.taps = taps;
-    if (taps > 0 && (deform_sample_cols(taps) > N || (long long)taps * M * 160 >= (1ll << 32))) return TDRN_E_UNSUPPORTED;
-    const int tiles = (int)((M + 31) / 32), cgs = N / 256;
-    // 512 workgroups are resident at a time (125 VGPRs: two 8-wave workgroups per CU).  The grid is cgs x parts workgroups of
+    if (!ygemm_supported(256, q.N, dtype) || q.M <= 0 || q.M >= (1ll << 31)) return TDRN_E_UNSUPPORTED;
+    p.x = (const char *)q.x; p.w = (const char *)q.w; p.y = (char *)q.y;
+    p.M = (int)q.M; p.N = q.N; p.ycs = q.ycs; p.taps = q.taps;
+    if (q.taps > 0 && (deform_sample_cols(q.taps) > q.N || (long long)q.taps * q.M * 160 >= (1ll << 32))) return TDRN_E_UNSUPPORTED;
+    const int tiles = (int)((q.M + 31) / 32), cgs = q.N / 256;
+    // 512 workgroups are resident at a time (125 VGPRs: two 8-wave workgroups per CU).  A problem is cgs x parts workgroups of
     // ceil(tiles / parts) tiles each; a partition is at least 8 tiles (the weight prologue is 8 KiB per wave).  The number of
     // partitions is the candidate that minimises rounds x tiles per workgroup (measured with 256 / 512 / 768 / 1024 assumed slots:
     // the 20x20 level 45.6 / 36.0 / 44.4 / 44.1 us, the 40x40 level 123-126 us whatever the partitioning -- it is not bound by
@@ -697,19 +711,49 @@ int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int 
     }
     p.parts = parts;
     p.tiles_per_part = (tiles + parts - 1) / parts;
-    dim3 grid((unsigned)cgs, (unsigned)parts);
+    blocks = cgs * parts;
+    return TDRN_OK;
+}
+
+int launch_ygemm_multi(const YGemmProblem *pr, int n, int dtype, hipStream_t s)
+{
+    if (!pr || n < 1 || n > 4) return TDRN_E_ARG;
+    YGemmMulti mp;
+    mp.n = 0;
+    mp.block_start[0] = 0;
+    // largest problem first: its workgroups are dispatched first, the small levels fill the tail
+    int order[4] = {0, 1, 2, 3};
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (pr[order[j]].M > pr[order[i]].M) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int i = 0; i < n; ++i) {
+        if (pr[order[i]].M <= 0) continue;
+        int blocks = 0;
+        TDRN_TRY(ygemm_fill(pr[order[i]], dtype, mp.p[mp.n], blocks));
+        mp.block_start[mp.n + 1] = mp.block_start[mp.n] + blocks;
+        ++mp.n;
+    }
+    if (mp.n == 0) return TDRN_OK;
+    for (int i = mp.n; i < 4; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
+    dim3 grid((unsigned)mp.block_start[mp.n]);
     static int ct = -1;
     // CT = 2 (four waves x 64 columns: half the LDS reads per output) measured 337-344 us against 332-334 us for the pair of deform
     // launches (round 4, interleaved): the transform is not bound by its LDS reads; the round-3 shape stays the default
     if (ct < 0) { const char *e = getenv("TDRN_YGEMM_CT"); ct = e ? atoi(e) : 1; }
     if (ct == 1) {
-        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 1>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 1>), grid, dim3(512), 0, s, p);
+        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 1>), grid, dim3(512), 0, s, mp);
+        else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 1>), grid, dim3(512), 0, s, mp);
     } else {
-        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 2>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 2>), grid, dim3(256), 0, s, p);
+        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 2>), grid, dim3(256), 0, s, mp);
+        else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 2>), grid, dim3(256), 0, s, mp);
     }
     return hip_status(hipGetLastError());
+}
+
+int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s, int taps)
+{
+    const YGemmProblem q{x, w, y, M, N, ycs, taps};
+    return launch_ygemm_multi(&q, 1, dtype, s);
 }
 
 // the fast path takes: 16-bit, stride 1, one deformable group, at most two branches with at most 34 taps together, Cout <= 80

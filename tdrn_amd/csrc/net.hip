@@ -1417,6 +1417,12 @@ struct tdrn_net {
                         for (int b0 = 0; b0 < B && rc == TDRN_OK; b0 += Bc) {
                             const int nb = B - b0 < Bc ? B - b0 : Bc;
                             DeformArgs ca[4];
+                            YGemmProblem yq[4];
+                            int n_yq = 0;
+                            bool all_ygemm = true;
+                            for (int i = 0; i < n_dargs; ++i) all_ygemm = all_ygemm && ygemm_supported(ops[ts_op[i]].Cin, ops[ts_op[i]].y_cols, cfg.dtype);
+                            static int ymulti = -1;
+                            if (ymulti < 0) { const char *e = getenv("TDRN_YGEMM_MULTI"); ymulti = e ? atoi(e) : 1; }
                             for (int i = 0; i < n_dargs && rc == TDRN_OK; ++i) {
                                 const Op &d = ops[ts_op[i]];
                                 DeformArgs &c = ca[i];
@@ -1430,7 +1436,9 @@ struct tdrn_net {
                                 int taps = 0;
                                 for (int k = 0; k < c.n_branches; ++k) taps += c.br[k].kh * c.br[k].kw;
                                 void *ybuf = tptr(ws, d.y_t, B);
-                                if (ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) {
+                                if (all_ygemm && ymulti) {       // all levels' transforms in ONE launch (below)
+                                    yq[n_yq++] = YGemmProblem{c.in, wb + d.wt_off, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, ts_tap_major ? taps : 0};
+                                } else if (ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) {
                                     rc = launch_ygemm(c.in, wb + d.wt_off, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, cfg.dtype, s, ts_tap_major ? taps : 0);
                                 } else {
                                     ConvArgs g;
@@ -1443,6 +1451,7 @@ struct tdrn_net {
                                 }
                                 ts_y[i] = ybuf; ts_cs[i] = d.y_cols;
                             }
+                            if (rc == TDRN_OK && n_yq > 0) rc = launch_ygemm_multi(yq, n_yq, cfg.dtype, s);
                             if (rc == TDRN_OK) rc = launch_deform_sample_multi(ca, ts_y, ts_cs, n_dargs, s, ts_tap_major);
                         }
                         n_dargs = 0;
