@@ -31,7 +31,7 @@ struct DeformParams {
     float *out0, *out1;
     long long o0_bs, o0_ps, o1_bs, o1_ps;
     int accumulate;   // 1: outputs are pre-zeroed and this problem atomically adds its partial result
-    int pad2_;
+    int g_begin, g_end;   // deformable groups [g_begin, g_end) of every tap (all of them unless the launch splits a problem by groups)
 };
 // several independent problems (the four pyramid levels) in ONE launch: their K loops are
 // latency-bound per workgroup, so running them side by side costs the time of the longest.
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
         for (int e = 0; e < 16; ++e) acc[ci][e] = 0.f;
 
     // K-loop cursor: branch, tap (ti,tj), group g, channel chunk cc inside the group
-    int br = 0, ti = 0, tj = 0, g = 0, cc = 0, kofs = 0;
+    int br = 0, ti = 0, tj = 0, g = p.g_begin, cc = 0, kofs = p.g_begin * (p.Cin / p.br[0].G);
     int coff[PA][4];      // element offsets of the four corners (relative to `in`)
     float cw[PA][4];      // bilinear weights (0 when the tap is rejected)
 
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
         for (int i = 0; i < PA; ++i) { offh[i] = noff[i][0]; offw[i] = noff[i][1]; }
         {   // the tap after this one (same stepping as advance())
             int nb = br, ni = ti, nj = tj, ng = g + 1;
-            if (ng == B.G) {
-                ng = 0;
+            if (ng == p.g_end) {
+                ng = p.g_begin;
                 if (++nj == B.kw) { nj = 0; ++ni; }
                 if (ni == B.kh) { ni = 0; ++nb; }
             }
@@ -227,13 +227,15 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
         kofs += CK;
         if (++cc < cpg / CK) return true;
         cc = 0;
-        if (++g == B.G) {
-            g = 0;
+        if (++g == p.g_end) {
+            g = p.g_begin;
             if (++tj == B.kw) { tj = 0; ++ti; }
             if (ti == B.kh) {
-                ti = 0; kofs = 0;
+                ti = 0;
                 if (++br == p.n_branches) return false;
             }
+            // K offset of (tap, first group of my range) in the weight row [taps][Cin] (the groups outside the range are skipped)
+            kofs = (ti * p.br[br].kw + tj) * p.Cin + p.g_begin * (p.Cin / p.br[br].G);
         }
         tap_params();
         return true;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
         }
     };
 
-    fetch_offsets(0, 0, 0, 0);
+    fetch_offsets(0, 0, 0, p.g_begin);
     tap_params();
     issue(0);
     latch_weights();
@@ -354,12 +356,17 @@ int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_
     DeformMulti mp;
     mp.n = 0;
     mp.block_start[0] = 0;
-    for (int pass = 0; pass < 2; ++pass) {           // pass 0: the longer branch of every problem, pass 1: the rest
+    // split_branches = 2: a ONE-branch problem with an even number >= 2 of deformable groups (the TRN temporal heads, df_group = 8)
+    // becomes two work items, groups [0, G/2) and [G/2, G), that atomically add into PRE-ZEROED outputs: its K loop (one step per
+    // (tap, group): 72 dependent steps with 8 groups, latency-bound per workgroup, ~100 workgroups at config #5's batch) halves and
+    // the workgroup count doubles.  Exactly two addends per output element: order-independent, deterministic.
+    for (int pass = 0; pass < 2; ++pass) {           // pass 0: the longer branch / first half of every problem, pass 1: the rest
         for (int i = 0; i < n; ++i) {
             if (args[i].dtype != args[0].dtype || args[i].Npad != args[0].Npad) return TDRN_E_UNSUPPORTED;
             DeformArgs a = args[i];
-            const bool two = a.n_branches == 2 && split_branches;
-            if (!two && pass == 1) continue;
+            const bool two = a.n_branches == 2 && split_branches == 1;
+            const bool halves = split_branches == 2 && a.n_branches == 1 && a.br[0].G >= 2 && a.br[0].G % 2 == 0;
+            if (!two && !halves && pass == 1) continue;
             if (two) {
                 const int t0 = a.br[0].kh * a.br[0].kw, t1 = a.br[1].kh * a.br[1].kw;
                 const int longer = t1 > t0 ? 1 : 0;
@@ -368,9 +375,15 @@ int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_
             }
             DeformParams p;
             TDRN_TRY(fill_params(a, p));
-            p.accumulate = two ? 1 : 0;
-            p.pad2_ = 0;
+            p.accumulate = (two || halves) ? 1 : 0;
+            p.g_begin = 0;
+            p.g_end = a.br[0].G;
+            if (halves) {
+                p.g_begin = pass == 0 ? 0 : a.br[0].G / 2;
+                p.g_end = pass == 0 ? a.br[0].G / 2 : a.br[0].G;
+            }
             if (p.M <= 0) continue;
+            if (mp.n >= kMaxDeformProblems) return TDRN_E_UNSUPPORTED;
             mp.p[mp.n] = p;
             mp.block_start[mp.n + 1] = mp.block_start[mp.n] + cdiv(p.M, 128);
             ++mp.n;

@@ -1161,7 +1161,9 @@ struct tdrn_net {
             int n_deform_groups = 0;
             for (size_t k = 0; k < ops.size(); ++k)
                 if (ops[k].kind == OP_DEFORM) {
-                    if (ops[k].n_branches == 2 && ops[k].y_t < 0 && !dsplit) dsplit = &ops[k];     // (the transform-then-sample path stores, no atomics)
+                    // (the transform-then-sample path stores, no atomics; the gather kernel splits two-branch problems by branch and
+                    // one-branch problems with an even number of deformable groups -- the TRN temporal heads -- by group halves)
+                    if ((ops[k].n_branches == 2 || (ops[k].G >= 2 && ops[k].G % 2 == 0)) && ops[k].y_t < 0 && !dsplit) dsplit = &ops[k];
                     if (k == 0 || ops[k - 1].kind != OP_DEFORM) ++n_deform_groups;
                 }
             if (dsplit && n_deform_groups == 1) {        // (one merged launch writes these outputs; nothing else does)
@@ -1458,8 +1460,8 @@ struct tdrn_net {
                         break;
                     }
                     if (!deform_batched) {      // all pyramid levels in one launch
-                        const bool split = o.n_branches == 2 && deform_split;
-                        if (split) {             // the two branches accumulate into zeroed outputs
+                        const int split = !deform_split ? 0 : (o.n_branches == 2 ? 1 : ((o.G >= 2 && o.G % 2 == 0) ? 2 : 0));
+                        if (split) {             // the two branches / the two halves of the groups accumulate into zeroed outputs
                             if (zeroed_early) {
                                 TDRN_HIP_TRY(hipStreamWaitEvent(s, ev_zero, 0));
                             } else {
@@ -1468,7 +1470,7 @@ struct tdrn_net {
                                 TDRN_HIP_TRY(hipMemsetAsync(io->conf, 0, (size_t)B * P * C * sizeof(float), s));
                             }
                         }
-                        rc = launch_deform_multi(dargs, n_dargs, s, split ? 1 : 0);
+                        rc = launch_deform_multi(dargs, n_dargs, s, split);
                         n_dargs = 0;
                     }
                     break;
