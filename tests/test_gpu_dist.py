@@ -87,3 +87,26 @@ def test_bench_py_launches_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "1", "--size", "333"],
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode != 0
+
+
+@pytest.mark.parametrize("config,batch", [(3, 2), (4, 4), (5, 2)])
+def test_bench_py_other_baseline_configs(config, batch):
+    """`bench.py --config N` (BASELINE.json configs 3-5; the driver's default command is config 2) prints the same line shape:
+    metric / value / roofline / cpu_baseline / parity, with the roofline bound the workload has (MFMA for the VGG nets and the TRN
+    clips, HBM for the MobileNet model) -- run here at a small batch so that it takes seconds."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--batch", str(batch), "--steps", "2",
+                        "--warmup", "1", "--reps", "2", "--cpu-frames", "2", "--no-modes", "--stream", "0"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == ("hbm" if config == 4 else "mfma") and 0 < r["frac"] < 1 and r["peak"] == (8000.0 if config == 4 else 2500.0)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["box_linf"] < 1.0 and "workload" in d["config"]
+    if config == 5:
+        assert abs(d["clips_per_s"] * 4 - d["value"]) / d["value"] < 1e-3
+        assert d["config"]["global_batch"] == batch * 4
