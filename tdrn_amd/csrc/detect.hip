@@ -292,7 +292,7 @@ __device__ __forceinline__ int wave_greedy_nms(int n, int cap, const NmsRule &r,
 // with 2.5 workgroups per CU.)  Returns min(*nk_s, cap).
 template <typename Get, typename Emit>
 __device__ __forceinline__ int block_greedy_nms(int n, int cap, const NmsRule &r, const KeepList &kept, unsigned char *alive_s,
-                                                int *nk_s, Box *rb, unsigned *kmw, Get get, Emit emit)
+                                                int *nk_s, Box *rb, unsigned *kmw, unsigned char *part_s, Get get, Emit emit)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
@@ -306,8 +306,28 @@ __device__ __forceinline__ int block_greedy_nms(int n, int cap, const NmsRule &r
         const int pos = c0 + tid;
         const bool valid = pos < n && wave < G;
         Box me = {0.f, 0.f, 0.f, 0.f, 1.f};
-        if (valid) get(pos, me);
-        const bool alive = valid && !suppressed_by(kept, 0, nk0, me, r);     // the long scan, spread over the waves
+        bool alive;
+        if (G >= 3) {
+            if (valid) get(pos, me);
+            alive = valid && !suppressed_by(kept, 0, nk0, me, r);           // the long scan, spread over the waves
+        } else {
+            // Near the cap a round takes one or two groups only: the idle waves take SLICES of the keep list for the same
+            // candidates (G = 1: four waves x a quarter of the list each; G = 2: two halves), the owner ORs the verdicts.  (Round 4:
+            // with ~170 boxes kept the one-group rounds spent ~11 us of a single wave in this scan.)  Same decisions.
+            const int S = G == 1 ? 4 : 2;
+            const int grp = wave % G, slice = wave / G;
+            const int pos_s = c0 + grp * 64 + lane;
+            Box cand = {0.f, 0.f, 0.f, 0.f, 1.f};
+            const bool valid_s = pos_s < n;
+            if (valid_s) get(pos_s, cand);
+            const int lo = nk0 * slice / S, hi = nk0 * (slice + 1) / S;
+            part_s[tid] = (valid_s && suppressed_by(kept, lo, hi, cand, r)) ? 1 : 0;
+            __syncthreads();
+            if (wave < G) me = cand;                                         // (slice 0 of group `wave`: my own candidate)
+            bool dead = false;
+            for (int q = 0; q < S; ++q) dead = dead || part_s[(wave + q * G) * 64 + lane] != 0;
+            alive = valid && !dead;
+        }
         alive_s[tid] = alive ? 1 : 0;
         rb[tid] = me;
         __syncthreads();
@@ -397,8 +417,8 @@ __device__ __forceinline__ float key_score(unsigned k)
 // Shared by both Detect kernels: sort the n keys in sk[] and continue the greedy NMS with them; survivors
 // are packed as [score, x1, y1, x2, y2] rows (normalised boxes, detection.py:59-62) as they are kept.
 __device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int top_k, const NmsRule &r, const KeepList &kept,
-                                            unsigned char *alive_s, int *nk_s, Box *rb, unsigned *kmw, const float *__restrict__ sb,
-                                            const float *__restrict__ nb, float *__restrict__ orow, long long *stamps)
+                                            unsigned char *alive_s, int *nk_s, Box *rb, unsigned *kmw, unsigned char *part_s,
+                                            const float *__restrict__ sb, const float *__restrict__ nb, float *__restrict__ orow, long long *stamps)
 {
     (void)stamps;
     int N = 64;
@@ -408,7 +428,7 @@ __device__ __forceinline__ int sort_and_nms(unsigned long long *sk, int n, int t
     bitonic_sort_desc(sk, N, threadIdx.x, 256);
     DT_STAMP(stamps, 4);
     return block_greedy_nms(
-        n, top_k, r, kept, alive_s, nk_s, rb, kmw,
+        n, top_k, r, kept, alive_s, nk_s, rb, kmw, part_s,
         [&](int pos, Box &bx) {
             const unsigned p = 0xFFFFFFFFu - (unsigned)(sk[pos] & 0xFFFFFFFFull);
             const f32x4 v = *(const f32x4 *)(sb + (size_t)p * 4);
@@ -608,7 +628,7 @@ __global__ __launch_bounds__(256) void detect_select_nms_kernel(const float *__r
         }
         __syncthreads();
         DT_STAMP(stamps, 3);
-        nk = sort_and_nms(sk, nsel, top_k, rule, kept, alive_s, ctl + 1, rb, kmw, sb, nb, orow, stamps);
+        nk = sort_and_nms(sk, nsel, top_k, rule, kept, alive_s, ctl + 1, rb, kmw, (unsigned char *)hist, sb, nb, orow, stamps);      // (the histogram is idle during the NMS)
         DT_STAMP(stamps, 5);
         taken += nsel;
         if (nk >= top_k || taken >= n) break;
