@@ -26,7 +26,7 @@ def short(name):
 
 def rows(d, kind):
     f = glob.glob(os.path.join(d, "**", "*_%s.csv" % kind), recursive=True)
-    return list(csv.DictReader(open(f[0]))) if f else []
+    return list(csv.DictReader(open(max(f, key=os.path.getmtime)))) if f else []      # (gpurun merges into existing directories: the newest run counts)
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     ks = glob.glob(os.path.join(src, "trace_graph", "**", "*_kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(dst, "kernel_stats_graph_replay.csv"))
+        shutil.copy(max(ks, key=os.path.getmtime), os.path.join(dst, "kernel_stats_graph_replay.csv"))
     line = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
     steps_in_pmc = 1 + 2 + 5 + 2 + 2      # warm-up 1 + timed 2 x 1 rep + forward-only 1 + 5 + the two profiled passes x 2 (bench.py); counted below instead
     per = collections.OrderedDict()

@@ -24,7 +24,7 @@ PEAK = 2500.0
 
 def trace_rows(d, kind):
     f = glob.glob(os.path.join(d, "**", "*_%s.csv" % kind), recursive=True)
-    return list(csv.DictReader(open(f[0]))) if f else []
+    return list(csv.DictReader(open(max(f, key=os.path.getmtime)))) if f else []      # (gpurun merges into existing directories: the newest run counts)
 
 
 def short(name):
@@ -54,7 +54,7 @@ def main():
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
     ks = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(dst, "kernel_stats.csv"))
+        shutil.copy(max(ks, key=os.path.getmtime), os.path.join(dst, "kernel_stats.csv"))
     # ---- per-op event timings -------------------------------------------------------------------------------
     ops = []
     for l in open(os.path.join(src, "per_op.txt")):
@@ -92,7 +92,7 @@ def main():
             graph_line = (sum(us) / len(us), len(us))
         ksg = glob.glob(os.path.join(src, "trace_graph", "**", "*_kernel_stats.csv"), recursive=True)
         if ksg:
-            shutil.copy(ksg[0], os.path.join(dst, "kernel_stats_graph_replay.csv"))
+            shutil.copy(max(ksg, key=os.path.getmtime), os.path.join(dst, "kernel_stats_graph_replay.csv"))
         if os.path.exists(os.path.join(src, "bench_traced_graph.json")):
             shutil.copy(os.path.join(src, "bench_traced_graph.json"), os.path.join(dst, "bench_traced_graph.json"))
     # ---- counters --------------------------------------------------------------------------------------------
