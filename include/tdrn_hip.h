@@ -178,7 +178,8 @@ TDRN_API int tdrn_detect_dev_scale(const float *loc, const float *conf, const fl
  *   Resize = OpenCV's INTER_LINEAR for 8-bit images (half-pixel centres, 11-bit fixed-point
  *   coefficients, uint8 result) restated from imgproc/resize.cpp; cv2 itself is not available in
  *   the build image, so this piece is "parity unpinned" by the reference: oracle.base_transform_u8 is
- *   pinned by hand-worked known-answer cases only (tests/test_oracle_pin.py). */
+ *   pinned by hand-worked known-answer cases and by staying within one grey level of torch's independent floating-point
+ *   bilinear (tests/test_oracle_pin.py); the device kernel is bit-exact against that oracle. */
 TDRN_API int tdrn_preprocess(const uint8_t *frames, int B, int H0, int W0, int S, const float mean_bgr[3],
                              int to_rgb, float *out, void *stream);
 

@@ -171,7 +171,9 @@ def base_transform_u8(image, size, mean_bgr, to_rgb=False):
     vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  PARITY UNPINNED BY THE REFERENCE: cv2 is not
     installed in the build image, so no output of cv2 itself exists to compare with.  What pins it instead are
     known-answer cases worked by hand from OpenCV's algorithm (tests/test_oracle_pin.py: identity, exact 2:1 = rounded
-    block mean, exact 1:2 = (512, 1536)/2048 weights with border clamp, a 3x3 -> 2x2 case through both fixed-point passes)."""
+    block mean, exact 1:2 = (512, 1536)/2048 weights with border clamp, a 3x3 -> 2x2 case through both fixed-point passes), and -- from
+    outside this repo -- the sampling geometry: within ONE grey level of torch's independent floating-point bilinear
+    (F.interpolate, align_corners=False) on random frames of six shape pairs."""
     img = np.asarray(image, np.uint8)
     if img.ndim == 3:
         img = img[None]

@@ -305,3 +305,24 @@ def test_preprocess_hand_computed_3x3_to_2x2():
     out = orc.base_transform_u8(img, 2, (0, 0, 0))[0]
     assert np.array_equal(out[0], np.asarray([[20, 35], [65, 80]], np.float32))
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], out[2])
+
+
+def test_preprocess_resize_within_one_lsb_of_an_independent_bilinear():
+    """cv2 itself is absent, so the fixed-point pipeline cannot be compared with cv2's output; what CAN be pinned from outside this
+    repo is the sampling geometry: torch's `F.interpolate(mode="bilinear", align_corners=False)` is an independent implementation of
+    the same half-pixel-centre, edge-replicating bilinear rule in floating point, and an 11-bit fixed-point evaluation of that rule
+    (coefficients rounded to 1/2048, two truncating shifts, one rounding) stays within ONE grey level of it -- on random uint8 frames,
+    up- and down-scaling, square and not (the VOC frame shape 375 x 500 -> 320 / 512 included).  A wrong source coordinate, a wrong
+    border rule or swapped coefficient pairs show as errors of tens of grey levels."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.Generator(np.random.PCG64(9))
+    for (h0, w0, s) in [(375, 500, 320), (375, 500, 512), (64, 48, 96), (33, 57, 40), (120, 120, 64), (7, 5, 16)]:
+        img = rng.integers(0, 256, (2, h0, w0, 3), dtype=np.uint8)
+        got = orc.base_transform_u8(img, s, (0, 0, 0))                         # (B,3,S,S), BGR order kept, mean 0
+        ref = F.interpolate(torch.from_numpy(img).permute(0, 3, 1, 2).double(), size=(s, s), mode="bilinear", align_corners=False).numpy()
+        d = np.abs(got.astype(np.float64) - ref)
+        assert d.max() <= 1.0 + 1e-9, (h0, w0, s, float(d.max()))
+        # ... and mostly it IS the rounded float result (the two truncating shifts of the vertical pass bias it down: 85-100 %)
+        assert np.mean(np.abs(got - np.rint(ref)) == 0) > 0.8, (h0, w0, s)
+        assert np.mean(got.astype(np.float64) - ref) < 0.0 + 0.05
