@@ -233,6 +233,8 @@ typedef struct {
                                        LDS; bit-identical; measured SLOWER than the two launches -- the depthwise conv on the vector ALU
                                        beside 128 live accumulators -- hence opt-in)                                                    */
 #define TDRN_PLAN_NO_PW1X1      1024 /* the wide 1x1 convs stay on conv_igemm.hip instead of dwpw.hip's persistent GEMM (pw1x1_kernel)     */
+#define TDRN_PLAN_NO_DW_SLIDE   2048 /* depthwise 3x3 layers on the one-row strip kernel instead of the sliding-window one (same bits)       */
+#define TDRN_PLAN_DW_SLIDE_ALL  4096 /* ... the sliding-window kernel (8-row segments) at every batch, also where it leaves CUs idle       */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 

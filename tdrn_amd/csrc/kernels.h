@@ -92,8 +92,9 @@ int launch_maxpool2(const void *in, void *out, int B, int H, int W, int C, int c
 int launch_l2norm(const void *in, const float *w, void *out, long long pixels, int C, int dtype,
                   hipStream_t s);
 // depthwise 3x3, pad 1, stride 1|2, folded BN + ReLU, NHWC DT.  w: fp32 [9][Cpad], bias [Cpad]
+// (kdisable bit 4: the one-row strip kernel instead of the sliding-window one, bit 5: the sliding-window one always -- same bits)
 int launch_dwconv3(const void *in, const float *w, const float *bias, void *out, int B, int H, int W,
-                   int C, int stride, int relu, int dtype, hipStream_t s);
+                   int C, int stride, int relu, int dtype, hipStream_t s, int kdisable = 0);
 // conv_dw block fused (dwpw.hip): depthwise 3x3 (stride 1, pad 1, fp32 weights [9][Cin] + bias [Cin], ReLU) -> pointwise 1x1
 // (DT weights [Npad][Cin], fp32 bias [Npad], ReLU) in one launch; the depthwise output stays in LDS.  16-bit types only.
 struct DwPwArgs {

@@ -516,14 +516,151 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(const char *__restri
     }
 }
 
+// Sliding-window version of the strip kernel: a thread keeps its TW-output strip and walks DOWN a segment of TH output rows
+// with the input rows it has already loaded kept in registers, so an input row is loaded once per segment (+ the segment's
+// halo rows) instead of once per output row that touches it.  Why: the strip kernel's consecutive output rows land in
+// different workgroups = different XCDs, each of which pulls the shared input rows through its own L2 -- FETCH_SIZE said 3.2
+// times the input of a stride-1 layer crossed the fabric (profiles/r04_cfg4/traffic_by_kernel.csv: 502 MB per launch for
+// 240 MB of tensor, 6.6 TB/s: the launch is bound by exactly that traffic).  The next row's loads are issued before the
+// current row's arithmetic.  Per output the taps are accumulated in the strip kernel's order: same bits.
+template <typename DT, int STRIDE, int TW>
+__global__ __launch_bounds__(256, 2) void dwconv3_slide_kernel(const char *__restrict__ in, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, char *__restrict__ out, int B,
+                                                            int H, int W, int Ho, int Wo, int C, int relu, int TH, int nseg)
+{
+    constexpr int P16 = elem_traits<DT>::per16;
+    constexpr int ES = elem_traits<DT>::bytes;
+    constexpr int NCOL = (TW - 1) * STRIDE + 3;
+    const int cpr = C / P16;
+    const int wg = (Wo + TW - 1) / TW;
+    const long long total = (long long)B * nseg * wg * cpr;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % cpr);
+    long long r = i / cpr;
+    const int sg = (int)(r % wg);
+    r /= wg;
+    const int seg = (int)(r % nseg);
+    const int b = (int)(r / nseg);
+    float wt[9][P16], bs[P16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < P16; ++j) wt[t][j] = w[(size_t)t * C + ch * P16 + j];
+#pragma unroll
+    for (int j = 0; j < P16; ++j) bs[j] = bias[ch * P16 + j];
+    const int wo0 = sg * TW;
+    const int ho0 = seg * TH, ho1 = ho0 + TH < Ho ? ho0 + TH : Ho;
+    const char *colp = in + ((size_t)b * H * W) * C * ES + (size_t)ch * 16;
+    struct Row { u32x4 v[NCOL]; };
+    auto load_row = [&](int hi) -> Row {                   // (a row outside the image is never USED: see `add_row`)
+        Row q;
+        const bool rok = (unsigned)hi < (unsigned)H;
+        const char *rowp = colp + (size_t)(rok ? hi : 0) * W * C * ES;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int wi = wo0 * STRIDE - 1 + c;
+            q.v[c] = (rok && (unsigned)wi < (unsigned)W) ? *(const u32x4 *)(rowp + (size_t)wi * C * ES) : u32x4{0u, 0u, 0u, 0u};
+        }
+        return q;
+    };
+    float acc[TW][P16];
+    auto add_row = [&](const Row &q, int rr, int hi) {
+        if ((unsigned)hi >= (unsigned)H) return;           // zero padding row: contributes nothing (as the strip kernel)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            float v[P16];
+            unpack16<DT>(q.v[c], v);
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                const int t = c - o * STRIDE;
+                if (t >= 0 && t < 3) {
+#pragma unroll
+                    for (int j = 0; j < P16; ++j) acc[o][j] = fmaf(wt[rr * 3 + t][j], v[j], acc[o][j]);
+                }
+            }
+        }
+    };
+    auto finish = [&](int ho) {
+#pragma unroll
+        for (int o = 0; o < TW; ++o) {
+            if (wo0 + o >= Wo) break;
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < P16; ++j) acc[o][j] = fmaxf(acc[o][j], 0.f);
+            }
+            *(u32x4 *)(out + ((((size_t)b * Ho + ho) * Wo + wo0 + o) * C + (size_t)ch * P16) * ES) = pack16<DT>(acc[o]);
+        }
+    };
+    auto start = [&]() {
+#pragma unroll
+        for (int o = 0; o < TW; ++o)
+#pragma unroll
+            for (int j = 0; j < P16; ++j) acc[o][j] = bs[j];
+    };
+    if (STRIDE == 1) {
+        Row ra = load_row(ho0 - 1), rb = load_row(ho0), rc = load_row(ho0 + 1);
+#pragma unroll 1
+        for (int ho = ho0; ho < ho1; ++ho) {
+            start();
+            add_row(ra, 0, ho - 1);
+            ra = load_row(ho + 2 < ho1 + 1 ? ho + 2 : -1);         // (into the registers of the row just used up; in flight under the
+            add_row(rb, 1, ho);                                    // other two rows' arithmetic; nothing past the segment)
+            add_row(rc, 2, ho + 1);
+            finish(ho);
+            const Row t = rb;
+            rb = rc; rc = ra; ra = t;
+        }
+    } else {
+        Row ra = load_row(2 * ho0 - 1), rb = load_row(2 * ho0), rc = load_row(2 * ho0 + 1);
+#pragma unroll 1
+        for (int ho = ho0; ho < ho1; ++ho) {
+            const bool more = ho + 1 < ho1;
+            Row nb = load_row(more ? 2 * ho + 2 : -1), nc = load_row(more ? 2 * ho + 3 : -1);
+            start();
+            add_row(ra, 0, 2 * ho - 1);
+            add_row(rb, 1, 2 * ho);
+            add_row(rc, 2, 2 * ho + 1);
+            finish(ho);
+            ra = rc; rb = nb; rc = nc;
+        }
+    }
+}
+
 int launch_dwconv3(const void *in, const float *w, const float *bias, void *out, int B, int H, int W, int C,
-                   int stride, int relu, int dtype, hipStream_t s)
+                   int stride, int relu, int dtype, hipStream_t s, int kdisable)
 {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int per16 = 16 / dtype_bytes(dtype);
     if (C % per16) return TDRN_E_UNSUPPORTED;
-    static int strip = -1;
+    static int strip = -1, slide = -1;
     if (strip < 0) { const char *e = getenv("TDRN_DW_STRIP"); strip = e ? atoi(e) : 1; }
+    if (slide < 0) { const char *e = getenv("TDRN_DW_SLIDE"); slide = e ? atoi(e) : 1; }
+    if (slide && !(kdisable & 16) && strip && (stride == 1 || stride == 2) && Wo >= 4) {
+        // strips of 4 outputs at stride 1, of 2 at stride 2 (9 input columns per row do not fit the registers of two waves per
+        // SIMD there).  Segment height: the tallest of 8 / 4 / 2 rows that still leaves >= 768 workgroups (3 per CU); below
+        // that the strip kernel (one row per thread).  Measured on dualrefinedet_mobilenet 320 x 64 (profiles/r04_experiments.md):
+        // 8 rows against 4 / 16: equal / 10-25 % slower; 2 waves per SIMD against a forced 3 (spills): 3x faster.
+        const int tw = stride == 1 ? 4 : 2;
+        const long long per_row = (long long)B * ((Wo + tw - 1) / tw) * (C / per16);
+        int th = 0;
+        for (int t = 8; t >= 2 && !th; t >>= 1)
+            if (per_row * ((Ho + t - 1) / t) >= 768ll * 256) th = t;
+        if (slide > 1) th = slide;                          // (experiments: a forced segment height)
+        if (kdisable & 32) th = 8;                          // (TDRN_PLAN_DW_SLIDE_ALL)
+        if (th) {
+            const int nseg = (Ho + th - 1) / th;
+            dim3 grid((unsigned)((per_row * nseg + 255) / 256));
+#define LD(DT)                                                                                                                          \
+    do {                                                                                                                                \
+        if (stride == 1) hipLaunchKernelGGL((dwconv3_slide_kernel<DT, 1, 4>), grid, dim3(256), 0, s, (const char *)in, w, bias, (char *)out, B, H, W, Ho, Wo, C, relu, th, nseg); \
+        else hipLaunchKernelGGL((dwconv3_slide_kernel<DT, 2, 2>), grid, dim3(256), 0, s, (const char *)in, w, bias, (char *)out, B, H, W, Ho, Wo, C, relu, th, nseg);             \
+    } while (0)
+            if (dtype == TDRN_F32) LD(float); else if (dtype == TDRN_BF16) LD(bf16_t); else LD(f16_t);
+#undef LD
+            return hip_status(hipGetLastError());
+        }
+    }
     if (strip && (stride == 1 || stride == 2) && Wo >= 4) {
         const long long total = (long long)B * Ho * ((Wo + 3) / 4) * (C / per16);
         dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));

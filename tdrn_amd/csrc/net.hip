@@ -674,7 +674,8 @@ struct tdrn_net {
     {
         es = dtype_bytes(cfg.dtype);
         kdisable = ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PP) ? 1 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PP_SK) ? 2 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0) |
+                   ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
@@ -1371,7 +1372,7 @@ struct tdrn_net {
                         }
                     }
                     rc = launch_dwconv3(tptr(ws, o.in, B), (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
-                                        tptr(ws, o.out, B), B, ti.H, ti.W, ti.Cpad, o.stride, o.relu, cfg.dtype, s);
+                                        tptr(ws, o.out, B), B, ti.H, ti.W, ti.Cpad, o.stride, o.relu, cfg.dtype, s, kdisable);
                     break;
                 }
                 case OP_REFLOC_IN:

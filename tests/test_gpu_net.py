@@ -819,3 +819,31 @@ def test_frame_stream_equals_unstreamed():
         fs.result(old)
     assert fs.result(last) is not None and int(last) == int(old)
     fs.drain()
+
+
+@pytest.mark.parametrize("model,args", [("dualrefinedet_mobilenet", (320, 21, 1, True)), ("ssd4scale_mobile", (320, 21, 1024, False))])
+def test_dw_sliding_window_equals_strip_kernel(model, args):
+    """The depthwise 3x3 layers of the MobileNet trunks (conv_dw, model/networks.py:736-745) run on one of two kernels: a thread
+    makes a 4-pixel strip of ONE output row (dwconv3_strip_kernel) or walks that strip down a segment of up to 8 rows keeping the
+    input rows in registers (dwconv3_slide_kernel, chosen when the launch still fills the chip: the batch decides).  Same tap
+    order per output, so the choice must not change a bit: plans that force either kernel and the default plan give identical
+    outputs, at batches on both sides of the switch, stride 1 and 2, segments and strips that end ragged (20 / 10 / 5 / 3-row maps,
+    24- and 12-pixel rows at 384), fp32 included."""
+    cases = [(320, 1), (320, 3), (320, 40), (384, 2), (512, 1)] + ([(256, 3)] if model == "ssd4scale_mobile" else [])
+    for dtype in ("bf16", "fp16", "fp32"):
+        nets = []
+        for flags in (0, _lib.PLAN_NO_DW_SLIDE, _lib.PLAN_DW_SLIDE_ALL):
+            net, _ = _build(model, args)
+            net.set_plan_flags(flags)
+            net.set_compute_dtype(dtype)
+            nets.append(net)
+        for size, batch in (cases if dtype != "fp32" else cases[:2]):
+            x = torch.from_numpy(synth.synth_frames(batch, size, seed=190 + size + batch)).to(DEV)
+            outs = [net(x) for net in nets]
+            for other in outs[1:]:
+                for u, v in zip(outs[0], other):
+                    if torch.is_tensor(u):
+                        assert torch.equal(u, v), (model, dtype, size, batch)
+                    elif u is not None:
+                        for uu, vv in zip(u, v):
+                            assert torch.equal(uu, vv), (model, dtype, size, batch)
