@@ -477,6 +477,7 @@ struct Pw1x1Params {
     int M, Cin, Cout, Cs, relu;
     int m_tiles, n_tiles, items;
     int ablate;                    // diagnostics (TDRN_PW_ABLATE): 1 no pixel DMA, 2 no weight DMA, 4 no LDS reads / MFMA, 8 no stores
+    int n_major;                   // item = nt * m_tiles + mt instead of mt * n_tiles + nt (see the kernel)
 };
 
 template <typename DT>
@@ -511,8 +512,12 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     if (n_items == 0) return;
     const int item0 = xcd * per_xcd + slot;
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane(dp_lds_addr(smem));
-    auto mt_of = [&](int item) -> int { return item % p.m_tiles; };
-    auto nt_of = [&](int item) -> int { return item / p.m_tiles; };
+    // item numbering: pixel-tile major by default -- the cout tiles of one pixel tile are neighbouring items of ONE XCD, dealt to
+    // neighbouring workgroups at the same time, so the pixel rows (the operand that streams from HBM) cross the fabric once; the
+    // whole weight matrix (<= 2 MB) stays in every XCD's L2.  (cout-tile major, conv3x3_pp.hip's choice for its 9x bigger weight
+    // matrices, fetched the activations once per cout tile: 185 MB for a 105-MB tensor, profiles/r04_cfg4.)
+    auto mt_of = [&](int item) -> int { return p.n_major ? item % p.m_tiles : item / p.n_tiles; };
+    auto nt_of = [&](int item) -> int { return p.n_major ? item / p.m_tiles : item % p.n_tiles; };
 
     // one chunk of an operand: wave w stages pixel rows [8(w + 8k), +8) / its group's weight rows, k = 0..3 (4 pieces each);
     // rows past M re-read the last row (their outputs are never stored)
@@ -780,6 +785,9 @@ int launch_pw1x1(const ConvArgs &a, hipStream_t s)
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("TDRN_PW_ABLATE"); ablate = e ? atoi(e) : 0; }
     p.ablate = ablate;
+    static int nmajor = -1;
+    if (nmajor < 0) { const char *e = getenv("TDRN_PW_NMAJOR"); nmajor = e ? atoi(e) : 0; }
+    p.n_major = nmajor;
     const int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
     if (a.dtype == TDRN_BF16) hipLaunchKernelGGL((pw1x1_kernel<bf16_t>), dim3(grid), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((pw1x1_kernel<f16_t>), dim3(grid), dim3(512), 0, s, p);
