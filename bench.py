@@ -336,24 +336,30 @@ def main_other(args):
         bcast_ms = bc1 + bc2
         FPC = 4                                                  # frames per clip = the key-frame interval
         det = [Detect(21, 0, 200, 0.01, 0.45) for _ in range(FPC)]
-        xb = [torch.from_numpy(synth.synth_frames(B * FPC, S, seed=100 + rank + 1000 * j)).to(dev).view(B, FPC, 3, S, S) for j in range(NB)]
+        # a step's clips FRAME-major: (FPC, B, 3, S, S) -- [0] = the B key frames, .view(FPC * B, ...) = all frames, frame i of clip i % B
+        xb = [torch.from_numpy(synth.synth_frames(B * FPC, S, seed=100 + rank + 1000 * j)).to(dev).view(FPC, B, 3, S, S) for j in range(NB)]
+        batched = args.trn_mode == "batched"
 
         def one_step(clips):
-            # evaluate_trn.py:438-467 over B clips at once: key frame -> static net (anchors + loc maps) -> temporal net
-            # (offsets from the loc maps); the following frames reuse the cached offsets; Detect per frame on the static anchors
-            s_loc, _, maps = stat(clips[:, 0].contiguous(), ret_loc=True)
+            # evaluate_trn.py:438-467 over B clips at once: key frame -> static net (anchors + loc maps) -> temporal net (offsets
+            # from the key frame's loc maps, reused by the frames up to the next key frame); Detect on the static anchors.
+            s_loc, _, maps = stat(clips[0], ret_loc=True)
+            if batched:
+                # the frames of an interval depend on the key frame only through its offsets: ONE temporal forward over all
+                # FPC * B frames (tdrn_net_io.reserved[1]: frame i reads the offsets of key frame i % B) and one Detect call
+                loc, conf = temp(clips.view(FPC * B, 3, S, S), ref_loc=maps)[:2]
+                return conf if args.no_detect else det[0].forward(loc, conf, pri, arm_loc_data=s_loc.repeat(FPC, 1, 1), scale=scale)
             outs, offs = [], None
-            for f in range(FPC):
-                xf = clips[:, f].contiguous()
+            for f in range(FPC):                       # the reference's order: frame by frame, offset_list cached from the key frame
                 if f == 0:
-                    loc, conf, offs = temp(xf, ref_loc=maps, ret_off=True)
+                    loc, conf, offs = temp(clips[f], ref_loc=maps, ret_off=True)
                 else:
-                    loc, conf = temp(xf, offset_list=offs)
+                    loc, conf = temp(clips[f], offset_list=offs)
                 outs.append(conf if args.no_detect else det[f].forward(loc, conf, pri, arm_loc_data=s_loc, scale=scale))
             return outs
         frames_per_step = B * FPC
         gflop_step = B * (SSD4SCALE_VGG_GFLOP + FPC * SSD4SCALE_VGG_GFLOP)     # (plain heads ~ deformable heads in FLOPs: same taps, same channels)
-        engines = [(eng_s, 1), (eng_t, FPC)]
+        engines = [(eng_s, 1), (eng_t, 1 if batched else FPC)]
         name = "TRN ssd4scale_vgg static + temporal (deform, 8 groups)"
     else:
         net, sd, eng, bcast_ms = make("dualrefinedet_mobilenet", (S, 21), dict(def_groups=1, multihead=True), 0)
@@ -384,14 +390,16 @@ def main_other(args):
     def fwd_only():
         if trn:
             clips = xb[0]
-            _, _, maps = stat(clips[:, 0].contiguous(), ret_loc=True)
+            _, _, maps = stat(clips[0], ret_loc=True)
+            if batched:
+                temp(clips.view(FPC * B, 3, S, S), ref_loc=maps)
+                return
             offs = None
             for f in range(FPC):
-                xf = clips[:, f].contiguous()
                 if f == 0:
-                    _, _, offs = temp(xf, ref_loc=maps, ret_off=True)
+                    _, _, offs = temp(clips[f], ref_loc=maps, ret_off=True)
                 else:
-                    temp(xf, offset_list=offs)
+                    temp(clips[f], offset_list=offs)
         else:
             eng.forward(xb[0])
     fwd_only()
@@ -468,7 +476,8 @@ def main_other(args):
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE config #%d: %s %dx%d, %s, %s per GPU, forward%s, synthetic VOC-shaped frames + synthetic weights" % (
-                       args.config, name, S, S, args.dtype, ("%d clips x 4 frames (1 static + 4 temporal forwards + 4 Detect per clip)" % B) if trn else "batch %d" % B,
+                       args.config, name, S, S, args.dtype, (("%d clips x 4 frames (per step: 1 static forward over the %d key frames, ONE temporal forward over the %d frames with the key frames' offsets, one Detect call)" % (B, B, 4 * B)) if batched else
+                                                       ("%d clips x 4 frames (per step: 1 static + 4 temporal forwards of %d frames + 4 Detect calls, frame by frame as evaluate_trn.py)" % (B, B))) if trn else "batch %d" % B,
                        "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
                    "global_batch": world * frames_per_step, "parallelism": "%s-sharded x%d, no per-frame collective" % ("clip" if trn else "frame", world),
                    "launch": "hipGraph replay" if args.graph else "eager", "resident_batches": NB},
@@ -480,6 +489,7 @@ def main_other(args):
     }
     if trn:
         line["clips_per_s"] = round(fps / FPC, 2)
+        line["trn_mode"] = args.trn_mode      # batched: one temporal forward per step (key-frame offsets broadcast); frames: one per frame index
     # ---- parity of the timed dtype against the fp32 CPU oracle on one frame / one clip (decoded boxes, scores) ----
     if not args.no_parity:
         from oracle import net_ref
@@ -559,6 +569,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=11)           # evaluate.py:463 drops the first 11 frames
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = the headline)")
+    ap.add_argument("--trn-mode", default="batched", choices=["batched", "frames"],
+                    help="config 5: 'batched' = one temporal forward over all frames of the step's clips (key-frame offsets broadcast); 'frames' = one temporal forward per frame index, the reference loop's order")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])

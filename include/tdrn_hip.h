@@ -284,7 +284,12 @@ typedef struct {
     /* reserved[0] != NULL, ssd4scale deform=1 only: REUSE the deformable offsets the previous forward of this net computed in
      * this workspace at this batch size instead of recomputing them from ref_loc (the reference's cached offset_list of the frames
      * between two key frames, evaluate_trn.py:459-462: offsets are a function of the key frame's loc maps only).  ref_loc may then
-     * be NULL; TDRN_E_STATE when no such forward came before (other workspace, other batch). */
+     * be NULL; TDRN_E_STATE when no such forward came before (other workspace, other batch).
+     * reserved[1] != NULL, ssd4scale deform=1 only: KEY-FRAME BROADCAST -- (intptr_t) reserved[1] = Bk, the number of key frames:
+     * ref_loc (and the optional `offsets` outputs) hold Bk samples and frame b of the batch uses the offsets of key frame b % Bk,
+     * i.e. the batch is n = B / Bk frames of each of Bk clips in frame-major order.  One forward then does what the reference's
+     * loop does frame by frame with its cached offset_list (evaluate_trn.py:452-462): the frames of an interval depend on the key
+     * frame only through those offsets.  TDRN_E_ARG unless 1 <= Bk <= B and B % Bk == 0. */
     void *reserved[4];
 } tdrn_net_io;
 

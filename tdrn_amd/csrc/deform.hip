@@ -22,6 +22,7 @@ struct DeformBranchP {
     const char *w;
     int off_stride, kh, kw, G;
     int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;      // per axis, like deform_conv_cuda.c:98-103
+    int off_rows, off_row0;                                  // DeformBranch: offsets of off_rows key-frame pixel rows, broadcast
 };
 struct DeformParams {
     const char *in, *zero;
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
             ho_[i] = rem / p.Wo;
             wo_[i] = rem - ho_[i] * p.Wo;
             ibase[i] = b * p.H * p.W * p.Cin;
-            mrow[i] = m;
+            // (the row of the offset maps this output pixel reads: its own, or under the key-frame broadcast of DeformBranch the
+            // key frame's -- both branches of a problem share the mapping)
+            mrow[i] = p.br[0].off_rows ? (m + p.br[0].off_row0) % p.br[0].off_rows : m;
         } else {
             ho_[i] = 0; wo_[i] = 0; ibase[i] = 0; mrow[i] = -1;
         }
@@ -334,7 +337,8 @@ static int fill_params(const DeformArgs &a, DeformParams &p)
         if (b.kh < 1 || b.kw < 1 || b.stride < 1 || b.dil < 1) return TDRN_E_SHAPE;
         p.br[i] = DeformBranchP{b.off, (const char *)b.w, b.off_stride, b.kh, b.kw, b.G,
                                 b.pad, b.pad_w < 0 ? b.pad : b.pad_w, b.stride, b.stride_w < 1 ? b.stride : b.stride_w,
-                                b.dil, b.dil_w < 1 ? b.dil : b.dil_w};
+                                b.dil, b.dil_w < 1 ? b.dil : b.dil_w, b.off_rows, b.off_row0};
+        if (b.off_rows < 0 || b.off_row0 < 0) return TDRN_E_ARG;
     }
     if (a.n_branches == 1) p.br[1] = p.br[0];
     p.M = a.B * a.Ho * a.Wo;
@@ -419,6 +423,7 @@ int launch_deform(const DeformArgs &a, hipStream_t s) { return launch_deform_mul
 struct SampleBranchP {
     const float *off;              // offsets of this branch: [pixel][off_stride], 2 floats per tap (dh, dw)
     int off_stride, kh, kw, pad_h, pad_w, dil_h, dil_w, col0;   // col0: first Y column block (tap index) of the branch
+    int off_rows, off_row0;        // DeformBranch: key-frame broadcast of the offsets (0: one row per output pixel)
 };
 struct SampleParams {
     const char *y;                 // [B*H*W][ycs] DT: tap t's 80 columns at t*80
@@ -465,7 +470,8 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
         const SampleBranchP &B = p.br[brn];
         const int tl = lane - (brn ? p.br[0].kh * p.br[0].kw : 0);
         const int ti = tl / B.kw, tj = tl - ti * B.kw;
-        const float *op = B.off + (size_t)m * B.off_stride + 2 * tl;
+        const int orow = B.off_rows ? (m + B.off_row0) % B.off_rows : m;
+        const float *op = B.off + (size_t)orow * B.off_stride + 2 * tl;
         const float offset_h = op[0], offset_w = op[1];
         float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
         int q1 = 0, q2 = 0, q3 = 0, q4 = 0;
@@ -811,7 +817,7 @@ int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, con
         int col0 = 0;
         for (int k = 0; k < a.n_branches; ++k) {
             const DeformBranch &b = a.br[k];
-            p.br[k] = SampleBranchP{b.off, b.off_stride, b.kh, b.kw, b.pad, b.pad_w < 0 ? b.pad : b.pad_w, b.dil, b.dil_w < 1 ? b.dil : b.dil_w, col0};
+            p.br[k] = SampleBranchP{b.off, b.off_stride, b.kh, b.kw, b.pad, b.pad_w < 0 ? b.pad : b.pad_w, b.dil, b.dil_w < 1 ? b.dil : b.dil_w, col0, b.off_rows, b.off_row0};
             col0 += b.kh * b.kw;
         }
         if (a.n_branches == 1) p.br[1] = p.br[0];

@@ -146,6 +146,9 @@ struct DeformBranch {
     const void *w = nullptr;
     int kh = 3, kw = 3, pad = 1, stride = 1, dil = 1, G = 1;      // pad / stride / dil: the H axis
     int pad_w = -1, stride_w = -1, dil_w = -1;                     // W axis; < 0 (< 1): same as the H axis
+    // key-frame broadcast (TRN clips): `off` holds off_rows pixel rows (the key frames' maps) and output pixel m of the launch reads row
+    // (off_row0 + m) % off_rows; 0 = one row per output pixel
+    int off_rows = 0, off_row0 = 0;
 };
 struct DeformArgs {
     const void *in = nullptr, *zero_page = nullptr;

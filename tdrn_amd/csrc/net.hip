@@ -176,7 +176,7 @@ struct tdrn_net {
     int plan_error = TDRN_OK;
     int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
     const void *offs_ws = nullptr;      // ssd4scale deform: the workspace / batch whose offset tensors the last forward filled
-    int offs_batch = 0;
+    int offs_batch = 0, offs_key_batch = 0;
     int dev = -1;                       // the device the pooled handles below belong to (the one current at the first forward)
     unsigned *status = nullptr;         // host-visible status words (pinned; tdrn_net_check): [0] chained split, [1] chain launch
     int kdisable = 0, fault_handoff = 0;
@@ -1240,7 +1240,15 @@ struct tdrn_net {
         bool dwpw_done = false;
         const bool reuse_offsets = cfg.deform && io->reserved[0] != nullptr;
         if (reuse_offsets && (offs_ws != ws || offs_batch != B)) return TDRN_E_STATE;
-        if (cfg.deform && !reuse_offsets) { offs_ws = ws; offs_batch = B; }
+        // key-frame broadcast (tdrn_net_io.reserved[1]): ref_loc / the offset tensors hold Bk samples, sample b reads those of b % Bk
+        int Bk = B;
+        if (io->reserved[1]) {
+            const long long kb = (long long)(intptr_t)io->reserved[1];
+            if (!cfg.deform || kb < 1 || kb > B || B % kb) return TDRN_E_ARG;
+            Bk = (int)kb;
+        }
+        if (reuse_offsets && offs_key_batch != Bk) return TDRN_E_STATE;
+        if (cfg.deform && !reuse_offsets) { offs_ws = ws; offs_batch = B; offs_key_batch = Bk; }
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &o = ops[oi];
             bool skip = false;
@@ -1377,15 +1385,16 @@ struct tdrn_net {
                 }
                 case OP_REFLOC_IN:
                     if (!io->ref_loc[o.scale]) return TDRN_E_ARG;
-                    rc = launch_nchw_to_nhwc(io->ref_loc[o.scale], tptr(ws, o.out, B), B, 12, o.hw, 12, TDRN_F32, s);
+                    rc = launch_nchw_to_nhwc(io->ref_loc[o.scale], tptr(ws, o.out, B), Bk, 12, o.hw, 12, TDRN_F32, s);
                     break;
                 case OP_OFFSET: {
                     const float *loc;
                     long long bs, ps;
                     if (o.in >= 0) { loc = (const float *)tptr(ws, o.in, B); bs = (long long)o.hw * 12; ps = 12; }
                     else { loc = io->arm_loc + (size_t)scale_off[o.scale] * 4; bs = (long long)P * 4; ps = 12; }
+                    // (offsets from ref_loc maps exist for the Bk key frames only; from the net's own ARM loc for every sample)
                     rc = launch_offset_conv(loc, bs, ps, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
-                                            (float *)tptr(ws, o.out, B), B, o.hw, 12, o.off_n, s);
+                                            (float *)tptr(ws, o.out, B), o.in >= 0 ? Bk : B, o.hw, 12, o.off_n, s);
                     break;
                 }
                 case OP_DEFORM: {
@@ -1396,6 +1405,8 @@ struct tdrn_net {
                     const float *off = (const float *)tptr(ws, o.off_t, B);
                     a.br[0] = DeformBranch{off + o.off_c0[0], tf.C, wb + o.w_off, 3, 3, 1, 1, 1, o.G};
                     if (o.n_branches == 2) a.br[1] = DeformBranch{off + o.off_c0[1], tf.C, wb + o.w2_off, 5, 5, 2, 1, 1, o.G};
+                    if (Bk < B)
+                        for (int k = 0; k < o.n_branches; ++k) a.br[k].off_rows = Bk * ti.H * ti.W;
                     a.B = B; a.H = ti.H; a.W = ti.W; a.Cin = o.Cin; a.Ho = ti.H; a.Wo = ti.W; a.Cout = o.Cout; a.Npad = o.Npad;
                     float *locbase = o.out_kind == OUT_ARM_LOC ? io->arm_loc : io->odm_loc;
                     a.out0 = locbase + (size_t)scale_off[o.scale] * 4; a.o0_bs = (long long)P * 4; a.o0_ps = 12;
@@ -1433,7 +1444,10 @@ struct tdrn_net {
                                 const size_t px0 = (size_t)b0 * c.H * c.W;
                                 c.B = nb;
                                 c.in = (const char *)c.in + px0 * c.Cin * es;
-                                for (int k = 0; k < c.n_branches; ++k) c.br[k].off += px0 * c.br[k].off_stride;
+                                for (int k = 0; k < c.n_branches; ++k) {
+                                    if (c.br[k].off_rows) c.br[k].off_row0 = (int)(px0 % (size_t)c.br[k].off_rows);
+                                    else c.br[k].off += px0 * c.br[k].off_stride;
+                                }
                                 c.out0 += (size_t)b0 * c.o0_bs;
                                 c.out1 += (size_t)b0 * c.o1_bs;
                                 int taps = 0;
@@ -1482,7 +1496,7 @@ struct tdrn_net {
                 case OP_OFF_OUT: {
                     const Tensor &tf = tensors[o.in];
                     rc = launch_nhwc_to_nchw_f32((const float *)tptr(ws, o.in, B), (long long)tf.H * tf.W * tf.C, tf.C,
-                                                 io->offsets[o.scale], B, o.Cout, tf.H * tf.W, s);
+                                                 io->offsets[o.scale], Bk, o.Cout, tf.H * tf.W, s);
                     break;
                 }
                 case OP_LOC_OUT:

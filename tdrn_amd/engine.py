@@ -135,20 +135,30 @@ class NetEngine(object):
         io.odm_loc = odm_loc.data_ptr() if odm_loc is not None else None
         io.conf = conf.data_ptr()
         offsets, loc_maps, keep = None, None, [x]
+        # key-frame broadcast (TRN clips, tdrn_net_io.reserved[1]): ref_loc maps of Bk key frames for a batch of B = n * Bk frames in
+        # frame-major order -- frame i uses the offsets of key frame i % Bk
+        Bk = B
+        if ref_loc is not None and len(ref_loc) and ref_loc[0].size(0) != B:
+            Bk = int(ref_loc[0].size(0))
+            if not self.cfg.deform or Bk < 1 or B % Bk:
+                raise ValueError("ref_loc holds %d key frames for a batch of %d frames (needs a deform=True ssd4scale net and B %% Bk == 0)" % (Bk, B))
         if want_offsets:
             g18 = (8 if self.cfg.deform else self.cfg.def_groups) * 18
-            offsets = [torch.empty((B, g18, f, f), dtype=torch.float32, device=dev) for f in self.fm]
+            offsets = [torch.empty((Bk if self.cfg.deform else B, g18, f, f), dtype=torch.float32, device=dev) for f in self.fm]
             for i, t in enumerate(offsets):
                 io.offsets[i] = t.data_ptr()
         # TRN temporal nets: the offsets computed by an earlier forward of THIS engine in the same workspace at the same batch are
         # reused when the caller presents the token that forward handed out (tdrn_net_io.reserved[0])
         reuse = (reuse_offsets_token is not None and reuse_offsets_token is getattr(self, "_offs_token", None)
-                 and self._offs_key == (ws.data_ptr(), B))
+                 and self._offs_key[:2] == (ws.data_ptr(), B))
         if reuse:
             io.reserved[0] = 1
+            Bk = self._offs_key[2]
             ref_loc = None
         elif self.cfg.deform and ref_loc is not None:
-            self._offs_token, self._offs_key = object(), (ws.data_ptr(), B)
+            self._offs_token, self._offs_key = object(), (ws.data_ptr(), B, Bk)
+        if Bk != B:
+            io.reserved[1] = Bk
         if ref_loc is not None:
             for i, t in enumerate(ref_loc):
                 t = t.contiguous().float()

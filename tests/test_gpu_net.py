@@ -847,3 +847,38 @@ def test_dw_sliding_window_equals_strip_kernel(model, args):
                     elif u is not None:
                         for uu, vv in zip(u, v):
                             assert torch.equal(uu, vv), (model, dtype, size, batch)
+
+
+@pytest.mark.parametrize("model,targs", [("ssd4scale_vgg", (320, 21, 1024, True)), ("ssd4scale_mobile", (320, 21, 1024))])
+def test_trn_key_frame_broadcast_equals_the_frame_loop(model, targs):
+    """tdrn_net_io.reserved[1]: ONE temporal forward over all frames of a step's clips (frame-major; ref_loc maps of the Bk key frames
+    only, frame i uses the offsets of key frame i % Bk) against the reference's loop -- the key frame with ref_loc, every following
+    frame of the interval with the cached offset_list (evaluate_trn.py:452-462).  The frames depend on the key frame only through
+    those offsets, so every output is BIT-identical; so are the offsets handed out.  Also through the reuse token (a second batched
+    forward with the offsets left in the workspace), and the argument checks."""
+    for dtype in ("bf16", "fp32"):
+        stat, _ = _build(model, targs + (False,), seed=0)
+        temp, _ = _build(model, targs + (True,), seed=1)
+        for n in (stat, temp):
+            n.set_compute_dtype(dtype)
+        Bk, F = (3, 4) if dtype == "bf16" else (2, 2)
+        frames = torch.from_numpy(synth.synth_frames(F * Bk, 320, seed=41)).to(DEV).view(F, Bk, 3, 320, 320)      # frame-major
+        _, _, maps = stat(frames[0], ret_loc=True)
+        first = temp(frames[0], ref_loc=maps, ret_off=True)
+        loop = [first] + [temp(frames[f], offset_list=first[2]) for f in range(1, F)]
+        loop_loc = torch.cat([o[0] for o in loop], 0).clone()
+        loop_conf = torch.cat([o[1].view(Bk, -1, 21) for o in loop], 0).clone()
+        loop_offs = [t.clone() for t in first[2]]
+        all_frames = frames.view(F * Bk, 3, 320, 320)
+        got = temp(all_frames, ref_loc=maps, ret_off=True)
+        assert torch.equal(got[0], loop_loc), (model, dtype)
+        assert torch.equal(got[1].view(F * Bk, -1, 21), loop_conf), (model, dtype)
+        assert len(got[2]) == 4 and all(torch.equal(a, b) for a, b in zip(got[2], loop_offs))
+        # other frames of the same clips, offsets still in the workspace
+        more = torch.from_numpy(synth.synth_frames(F * Bk, 320, seed=43)).to(DEV)
+        again = temp(more, offset_list=got[2])
+        want = torch.cat([temp(more[f * Bk:(f + 1) * Bk], ref_loc=maps)[0] for f in range(F)], 0)
+        assert torch.equal(again[0], want), (model, dtype)
+        # a key-frame count that does not divide the batch is an argument error
+        with pytest.raises(ValueError):
+            temp(all_frames[:F * Bk - 1], ref_loc=maps)
