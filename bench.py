@@ -340,7 +340,7 @@ def main_other(args):
         xb = [torch.from_numpy(synth.synth_frames(B * FPC, S, seed=100 + rank + 1000 * j)).to(dev).view(FPC, B, 3, S, S) for j in range(NB)]
         batched = args.trn_mode == "batched"
 
-        def one_step(clips):
+        def one_step(clips, batched=batched):
             # evaluate_trn.py:438-467 over B clips at once: key frame -> static net (anchors + loc maps) -> temporal net (offsets
             # from the key frame's loc maps, reused by the frames up to the next key frame); Detect on the static anchors.
             s_loc, _, maps = stat(clips[0], ret_loc=True)
@@ -385,6 +385,23 @@ def main_other(args):
     reps = sorted(_timed(step, args.steps, max(1, args.reps), tdist, torch, dev))
     dt = reps[len(reps) // 2]
     fps = world * frames_per_step * args.steps / dt
+    # config 5, batched mode: the same clips in the reference loop's order (one temporal forward and one Detect per frame index),
+    # timed in the same process -- what the batching is worth
+    frame_loop = None
+    if trn and batched and not args.no_frame_loop:
+        loop_step = lambda clips: one_step(clips, batched=False)
+        if args.graph:
+            lg = [GraphedCall(loop_step, xb[j]) for j in range(NB)]
+            KEEP_ALIVE.append(lg)
+            lstep = lambda k: lg[k % NB](lg[k % NB].inputs[0])
+        else:
+            lstep = lambda k: loop_step(xb[k % NB])
+        for k in range(args.warmup):
+            lstep(k)
+        lr = sorted(_timed(lstep, args.steps, max(1, min(3, args.reps)), tdist, torch, dev))
+        ldt = lr[len(lr) // 2]
+        frame_loop = {"frames_per_s": round(world * frames_per_step * args.steps / ldt, 2), "ms_per_step": round(ldt / args.steps * 1e3, 4),
+                      "what": "1 static + 4 temporal forwards of %d frames + 4 Detect calls per step (--trn-mode frames)" % B}
 
     # forward-only time of a step (eager, no Detect), and the per-family accounting of one step
     def fwd_only():
@@ -490,6 +507,8 @@ def main_other(args):
     if trn:
         line["clips_per_s"] = round(fps / FPC, 2)
         line["trn_mode"] = args.trn_mode      # batched: one temporal forward per step (key-frame offsets broadcast); frames: one per frame index
+        if frame_loop is not None:
+            line["frame_by_frame"] = frame_loop
     # ---- parity of the timed dtype against the fp32 CPU oracle on one frame / one clip (decoded boxes, scores) ----
     if not args.no_parity:
         from oracle import net_ref
@@ -569,6 +588,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=11)           # evaluate.py:463 drops the first 11 frames
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = the headline)")
+    ap.add_argument("--no-frame-loop", action="store_true", help="config 5, batched mode: skip the side measurement of the frame-by-frame order")
     ap.add_argument("--trn-mode", default="batched", choices=["batched", "frames"],
                     help="config 5: 'batched' = one temporal forward over all frames of the step's clips (key-frame offsets broadcast); 'frames' = one temporal forward per frame index, the reference loop's order")
     ap.add_argument("--batch", type=int, default=None)

@@ -11,10 +11,10 @@ OUT=${2:-gpurun_out/r04_cfg$CFG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py --config $CFG > $OUT/bench.json 2> $OUT/bench.err
-python3 bench.py --config $CFG --per-op --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 > $OUT/bench_per_op.json 2> $OUT/per_op.txt
-COMMON="--config $CFG --steps 5 --warmup 3 --reps 3 --no-cpu-baseline --no-parity --no-modes --stream 0"
+python3 bench.py --config $CFG --per-op --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 --no-frame-loop > $OUT/bench_per_op.json 2> $OUT/per_op.txt
+COMMON="--config $CFG --steps 5 --warmup 3 --reps 3 --no-cpu-baseline --no-parity --no-modes --stream 0 --no-frame-loop"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_graph -- python3 bench.py $COMMON --graph 1 > $OUT/bench_traced_graph.json 2> $OUT/trace_graph.err
-PM="--config $CFG --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 --no-detect"
+PM="--config $CFG --steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 --no-detect --no-frame-loop"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PM > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PM > /dev/null 2> $OUT/pmc_write.err
 find $OUT -name "*.csv" | head; tail -2 $OUT/bench.err

@@ -56,7 +56,8 @@ def main():
     first = [k for k in per if k.startswith("first_conv") or k.endswith("true>")]
     n_fwd = max([per[k]["n"].get("FETCH_SIZE", 0) for k in first] or [1])
     if line["config"]["workload"].startswith("BASELINE config #5"):
-        n_fwd = max(1, n_fwd // 5)                    # a step = 1 static + 4 temporal forwards
+        # a step = 1 static + 4 temporal forwards, or (batched mode) 1 static + ONE temporal forward over all frames
+        n_fwd = max(1, n_fwd // (2 if line.get("trn_mode") == "batched" else 5))
     out = []
     tot_b = tot_us = 0.0
     for k, e in per.items():

@@ -36,3 +36,20 @@ class TRNDriver(object):
         dets = self.detector.forward(out[0], out[1], self.priors, arm_loc_data=self.static_out[0], scale=scale)
         self.current_i += 1
         return dets
+
+    def clips(self, frames, scale=None):
+        """Offline evaluation of whole intervals: `frames` (F, Bk, 3, S, S) = the F <= interval consecutive frames of Bk clips,
+        FRAME-major ([0] = the key frames).  One static forward over the Bk key frames, ONE temporal forward over all F * Bk frames
+        (tdrn_net_io.reserved[1]: frame i reads the offsets of key frame i % Bk) and one Detect call on the static anchors --
+        the same detections, bit for bit, as `step` frame by frame (within an interval a frame depends on the key frame only
+        through the cached offsets and anchors, evaluate_trn.py:452-462), at the throughput of one batch of F * Bk frames.
+        Returns the Detect output (F * Bk, C, top_k, 5), frame-major; the per-stream state of `step` is not touched."""
+        if frames.dim() != 5 or frames.size(0) > self.interval:
+            raise ValueError("frames must be (F <= interval, clips, 3, S, S), got %r" % (tuple(frames.shape),))
+        F, Bk = int(frames.size(0)), int(frames.size(1))
+        static_out = list(self.static_net(frames[0], ret_loc=self.deform))
+        anchors = static_out[0] * self.loose
+        allf = frames.reshape(F * Bk, *frames.shape[2:])
+        out = self.net(allf, ref_loc=static_out[2]) if self.deform else self.net(allf)
+        self.key_frames += Bk
+        return self.detector.forward(out[0], out[1], self.priors, arm_loc_data=anchors.repeat(F, 1, 1), scale=scale)

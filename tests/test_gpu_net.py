@@ -524,6 +524,16 @@ def test_trn_driver_key_frame_protocol():
     assert torch.equal(outs[5], det.forward(t5[0], t5[1], pri, arm_loc_data=s4[0]))
     drv.step(clip[0:1], video_name="v1")            # a new video forces a key frame
     assert drv.key_frames == 3 and drv.current_i == 1
+    # whole intervals of several clips at once (TRNDriver.clips): the same detections as the frame-by-frame protocol
+    two = torch.from_numpy(synth.synth_frames(8, 320, seed=43)).to(DEV).view(2, 4, 3, 320, 320)          # (clip, frame, ...)
+    want = []
+    for c in range(2):
+        d2 = TRNDriver(stat, temp, det, pri, interval=4, loose=1.0, deform=True)
+        want.append([d2.step(two[c, f:f + 1], video_name="c%d" % c).clone() for f in range(4)])
+    got = drv.clips(two.transpose(0, 1).contiguous())                                                   # frame-major
+    for f in range(4):
+        for c in range(2):
+            assert torch.equal(got[f * 2 + c], want[c][f][0]), (f, c)
 
 
 @pytest.mark.parametrize("size,mh", [(192, False), (384, True)])
