@@ -484,6 +484,42 @@ def main_other(args):
                     "dominant_family": {"name": dom["name"], "ms": round(dom["ms"], 4), "gbyte_per_s": round(dom["bytes"] / 1e9 / (dom["ms"] * 1e-3), 1),
                                         "tflop_per_s": round(dom["flops"] / 1e12 / (dom["ms"] * 1e-3), 1)}}
 
+    # ---- config 4, the streamed mode ("test_video-style stream"): uint8 frames come from the host, detections go back ----------
+    stream_blk = None
+    if not trn and args.stream and not args.no_detect:
+        from tdrn_amd.stream import FrameStream
+        NSL = 3
+        fs = FrameStream(eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NSL)
+        rng = np.random.RandomState(7)
+        for sl in range(NSL):
+            fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
+        fs.prime()
+        for k in range(2 * NSL):
+            fs.run()
+        fs.drain()
+        t_stream = []
+        for _ in range(max(3, args.reps // 2)):
+            tdist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                fs.run()
+            fs.drain()
+            tdist.barrier()
+            t_stream.append(tdist.max_over_ranks(time.perf_counter() - t0, dev))
+        t_stream.sort()
+        ts = t_stream[len(t_stream) // 2]
+        fs.prime()
+        got = fs.result(fs.run()).clone()
+        want = fs.eager(fs.pinned_in(0).to(dev)).cpu()
+        stream_blk = {"frames_per_s": round(world * B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
+                      "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
+                      "copy_streams_picked": (fs.calibration or {}).get("picked"),
+                      "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
+                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | caller's stream: one hipGraph per slot = tdrn_preprocess, net, Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
+                                  % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL)}
+        KEEP_ALIVE.append(fs)
+
     if rank != 0:
         tdist.barrier()
         return
@@ -509,6 +545,8 @@ def main_other(args):
         line["trn_mode"] = args.trn_mode      # batched: one temporal forward per step (key-frame offsets broadcast); frames: one per frame index
         if frame_loop is not None:
             line["frame_by_frame"] = frame_loop
+    if stream_blk is not None:
+        line["stream"] = stream_blk
     # ---- parity of the timed dtype against the fp32 CPU oracle on one frame / one clip (decoded boxes, scores) ----
     if not args.no_parity:
         from oracle import net_ref
