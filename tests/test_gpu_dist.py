@@ -89,6 +89,29 @@ def test_bench_py_launches_its_own_ranks():
     assert p.returncode != 0
 
 
+@pytest.mark.parametrize("config,batch", [(4, 4), (5, 2)])
+def test_bench_py_other_configs_launch_their_own_ranks(config, batch):
+    """`python bench.py --config N --gpus 2` (the driver's command form, no torchrun variables): two ranks over gloo on this one
+    device, weights broadcast from rank 0, the frames / clips sharded by rank, one line from rank 0 with the whole-job rate --
+    config 4 with its streamed mode (every rank feeds its own slots), config 5 with the batched temporal forward."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TDRN_DIST_BACKEND="gloo", TDRN_DIST_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--gpus", "2", "--batch", str(batch), "--steps", "2",
+                        "--warmup", "1", "--reps", "2", "--no-cpu-baseline", "--no-parity"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    per_rank = batch * (4 if config == 5 else 1)
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["global_batch"] == 2 * per_rank and d["value"] > 0
+    assert abs(d["value"] - 2 * per_rank * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    if config == 4:
+        assert d["stream"]["detections_identical_to_unstreamed"] and d["stream"]["frames_per_s"] > 0
+    else:
+        assert d["trn_mode"] == "batched" and d["frame_by_frame"]["frames_per_s"] > 0
+
+
 @pytest.mark.parametrize("config,batch", [(3, 2), (4, 4), (5, 2)])
 def test_bench_py_other_baseline_configs(config, batch):
     """`bench.py --config N` (BASELINE.json configs 3-5; the driver's default command is config 2) prints the same line shape:
