@@ -41,6 +41,7 @@ struct DeformMulti {
     DeformParams p[kMaxDeformProblems];
     int block_start[kMaxDeformProblems + 1];
     int n;
+    int xcd_order;    // 1: the grid is 8 * ceil(tiles / 8) workgroups and workgroup b works on tile (b % 8) * ceil(tiles / 8) + b / 8 (see the kernel)
 };
 
 template <typename DT> struct MmaD;
@@ -65,10 +66,18 @@ template <> struct MmaD<float> {
 template <typename DT, int NTL>
 __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
 {
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; with `xcd_order` every XCD works on a CONTIGUOUS run of pixel tiles, so the
+    // rows that neighbouring tiles gather (the taps reach +-1..2 rows plus the offsets) come through one L2 instead of eight
+    int bid = (int)blockIdx.x;
+    if (mp.xcd_order) {
+        const int total = mp.block_start[mp.n], per = (total + 7) >> 3;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= total) return;                       // (whole workgroup; the grid is rounded up to 8 * per)
+    }
     int prob = 0;
 #pragma unroll
     for (int i = 1; i < kMaxDeformProblems; ++i)
-        if (i < mp.n && (int)blockIdx.x >= mp.block_start[i]) prob = i;
+        if (i < mp.n && bid >= mp.block_start[i]) prob = i;
     const DeformParams &p = mp.p[prob];
     constexpr int BM = 128, BN = NTL * 32, NT = 256, RPP = 32, PA = BM / RPP;
     constexpr int ES = elem_traits<DT>::bytes;
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256) void deform_gemm_kernel(const DeformMulti mp)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = t >> 3, pc = t & 7;
     const int lc16 = (pc ^ ((lrow >> 1) & 7)) << 4;
-    const int m0 = ((int)blockIdx.x - mp.block_start[prob]) * BM;
+    const int m0 = (bid - mp.block_start[prob]) * BM;
     const int HoWo = p.Ho * p.Wo;
 
     int ho_[PA], wo_[PA], ibase[PA];
@@ -310,7 +319,7 @@ int deform_n_pad(int cout) { return (int)align_up((size_t)cout, 32); }
 
 template <typename DT> static int launch_deform_dt(const DeformMulti &mp, int ntl, hipStream_t s)
 {
-    dim3 grid((unsigned)mp.block_start[mp.n]);
+    dim3 grid((unsigned)(mp.xcd_order ? 8 * ((mp.block_start[mp.n] + 7) / 8) : mp.block_start[mp.n]));
     switch (ntl) {
         case 1: hipLaunchKernelGGL((deform_gemm_kernel<DT, 1>), grid, dim3(256), 0, s, mp); break;
         case 2: hipLaunchKernelGGL((deform_gemm_kernel<DT, 2>), grid, dim3(256), 0, s, mp); break;
@@ -395,6 +404,9 @@ int launch_deform_multi(const DeformArgs *args, int n, hipStream_t s, int split_
     }
     if (mp.n == 0) return TDRN_OK;
     for (int i = mp.n; i < kMaxDeformProblems; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
+    static int xo = -1;
+    if (xo < 0) { const char *e = getenv("TDRN_DEFORM_XCD"); xo = e ? atoi(e) : 1; }
+    mp.xcd_order = xo;
     switch (args[0].dtype) {
         case TDRN_F32: return launch_deform_dt<float>(mp, args[0].Npad / 32, s);
         case TDRN_BF16: return launch_deform_dt<bf16_t>(mp, args[0].Npad / 32, s);
