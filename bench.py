@@ -383,6 +383,8 @@ def main_other(args):
     for k in range(args.warmup):
         step(k)
     reps = sorted(_timed(step, args.steps, max(1, args.reps), tdist, torch, dev))
+    for e_, _m in engines:
+        e_.check()                  # tdrn_net_check: a device-side hand-off that timed out inside the replays above fails the run HERE
     dt = reps[len(reps) // 2]
     fps = world * frames_per_step * args.steps / dt
     # config 5, batched mode: the same clips in the reference loop's order (one temporal forward and one Detect per frame index),
@@ -756,6 +758,8 @@ def main():
     for k in range(args.warmup):
         step(k)
     reps = sorted(timed(step, args.steps, max(1, args.reps)))
+    for e_ in engines:
+        e_.check()                  # tdrn_net_check: a device-side hand-off that timed out inside the replays above fails the run HERE
     dt = reps[len(reps) // 2]                                    # the median repetition
     fps = world * B * args.steps / dt
 
