@@ -316,9 +316,11 @@ def main_other(args):
     scale = [500.0, 375.0, 500.0, 375.0]
     trn = args.config == 5
 
-    def make(modname, a, kw, seed):
+    def make(modname, a, kw, seed, plan_flags=0):
         import importlib
         net = importlib.import_module("tdrn_amd.model." + modname).build_net("test", *a, **kw)
+        if plan_flags:
+            net.set_plan_flags(plan_flags)
         net.set_compute_dtype(args.dtype)
         sd = None
         if rank == 0:
@@ -331,7 +333,12 @@ def main_other(args):
         return net, sd, eng, (time.perf_counter() - t0) * 1e3
 
     if trn:
-        stat, sd_s, eng_s, bc1 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=False), 0)
+        # (overlapped mode: the static net runs on a second stream of the step's capture, and its plan uses that one stream only -- a
+        # forward that forks its own stream lanes from a stream which itself joined the capture by an event takes
+        # hipStreamEndCapture down on ROCm 7.2, scripts/dev/trn_overlap_probe.py)
+        overlap = args.trn_mode == "batched" and bool(args.trn_overlap)
+        stat, sd_s, eng_s, bc1 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=False), 0,
+                                      _lib.PLAN_ONE_STREAM if overlap else 0)
         temp, sd_t, eng_t, bc2 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=True), 1)
         bcast_ms = bc1 + bc2
         FPC = 4                                                  # frames per clip = the key-frame interval
@@ -339,10 +346,26 @@ def main_other(args):
         # a step's clips FRAME-major: (FPC, B, 3, S, S) -- [0] = the B key frames, .view(FPC * B, ...) = all frames, frame i of clip i % B
         xb = [torch.from_numpy(synth.synth_frames(B * FPC, S, seed=100 + rank + 1000 * j)).to(dev).view(FPC, B, 3, S, S) for j in range(NB)]
         batched = args.trn_mode == "batched"
+        trn_side, trn_ev = torch.cuda.Stream(dev), torch.cuda.Event()
+        KEEP_ALIVE.append((trn_side, trn_ev))
 
         def one_step(clips, batched=batched):
             # evaluate_trn.py:438-467 over B clips at once: key frame -> static net (anchors + loc maps) -> temporal net (offsets
             # from the key frame's loc maps, reused by the frames up to the next key frame); Detect on the static anchors.
+            if batched and args.trn_overlap:
+                # ... and the static net's forward (8 key frames: small launches that leave CUs idle) runs on a second stream BESIDE
+                # the temporal net's trunk, which does not depend on it; the temporal forward waits for the static net's event right
+                # before its first read of the loc maps (tdrn_net_io.reserved[2])
+                main = torch.cuda.current_stream(dev)
+                trn_side.wait_stream(main)
+                with torch.cuda.stream(trn_side):
+                    s_loc, _, maps = stat(clips[0], ret_loc=True)
+                    trn_ev.record(trn_side)     # (one event object for the process: destroyed inside a stream capture it takes hipStreamEndCapture down)
+                loc, conf = temp(clips.view(FPC * B, 3, S, S), ref_loc=maps, ref_event=trn_ev)[:2]
+                main.wait_stream(trn_side)
+                for t_ in [s_loc] + list(maps):
+                    t_.record_stream(main)
+                return conf if args.no_detect else det[0].forward(loc, conf, pri, arm_loc_data=s_loc.repeat(FPC, 1, 1), scale=scale)
             s_loc, _, maps = stat(clips[0], ret_loc=True)
             if batched:
                 # the frames of an interval depend on the key frame only through its offsets: ONE temporal forward over all
@@ -544,6 +567,7 @@ def main_other(args):
     }
     if trn:
         line["clips_per_s"] = round(fps / FPC, 2)
+        line["trn_static_net_overlapped"] = bool(batched and args.trn_overlap)
         line["trn_mode"] = args.trn_mode      # batched: one temporal forward per step (key-frame offsets broadcast); frames: one per frame index
         if frame_loop is not None:
             line["frame_by_frame"] = frame_loop
@@ -628,6 +652,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=11)           # evaluate.py:463 drops the first 11 frames
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = the headline)")
+    ap.add_argument("--trn-overlap", type=int, default=1, help="config 5, batched mode: 1 = the static net's forward runs on a second stream beside the temporal net's trunk")
     ap.add_argument("--no-frame-loop", action="store_true", help="config 5, batched mode: skip the side measurement of the frame-by-frame order")
     ap.add_argument("--trn-mode", default="batched", choices=["batched", "frames"],
                     help="config 5: 'batched' = one temporal forward over all frames of the step's clips (key-frame offsets broadcast); 'frames' = one temporal forward per frame index, the reference loop's order")

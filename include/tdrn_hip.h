@@ -289,7 +289,10 @@ typedef struct {
      * ref_loc (and the optional `offsets` outputs) hold Bk samples and frame b of the batch uses the offsets of key frame b % Bk,
      * i.e. the batch is n = B / Bk frames of each of Bk clips in frame-major order.  One forward then does what the reference's
      * loop does frame by frame with its cached offset_list (evaluate_trn.py:452-462): the frames of an interval depend on the key
-     * frame only through those offsets.  TDRN_E_ARG unless 1 <= Bk <= B and B % Bk == 0. */
+     * frame only through those offsets.  TDRN_E_ARG unless 1 <= Bk <= B and B % Bk == 0.
+     * reserved[2] != NULL, with ref_loc: a hipEvent_t that the stream producing the ref_loc maps (the static net's forward, running
+     * on ANOTHER stream beside this one) records when they are complete.  The forward waits for it right before its first read of
+     * ref_loc -- behind its trunk, which does not depend on the maps -- instead of the caller serialising the two forwards. */
     void *reserved[4];
 } tdrn_net_io;
 

@@ -1385,6 +1385,9 @@ struct tdrn_net {
                 }
                 case OP_REFLOC_IN:
                     if (!io->ref_loc[o.scale]) return TDRN_E_ARG;
+                    // (tdrn_net_io.reserved[2]: the loc maps are still being produced on another stream -- wait for its event HERE, not
+                    // at the start of the forward: the trunk above does not depend on them)
+                    if (io->reserved[2]) TDRN_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)io->reserved[2], 0));
                     rc = launch_nchw_to_nhwc(io->ref_loc[o.scale], tptr(ws, o.out, B), Bk, 12, o.hw, 12, TDRN_F32, s);
                     break;
                 case OP_OFFSET: {

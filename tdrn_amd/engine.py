@@ -104,7 +104,8 @@ class NetEngine(object):
         v = values.to(self.device, torch.float32).contiguous()
         check(self.lib.tdrn_net_write_tensor(self.handle, ptr(self._ws), v.size(0), index, ptr(v), _lib.current_stream(self.device)))
 
-    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None, reuse_offsets_token=None, first_op=0):
+    def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None, reuse_offsets_token=None, first_op=0,
+                ref_event=None):
         _lib.require_cuda(x, "input")
         if self.weights is None:
             raise RuntimeError("weights were never packed (load() / broadcast_weights())")
@@ -164,6 +165,9 @@ class NetEngine(object):
                 t = t.contiguous().float()
                 keep.append(t)
                 io.ref_loc[i] = t.data_ptr()
+            if ref_event is not None:
+                # a torch.cuda.Event recorded on the stream that is still producing `ref_loc` (tdrn_net_io.reserved[2])
+                io.reserved[2] = int(ref_event.cuda_event)
         if want_loc_maps:
             loc_maps = [torch.empty((B, 12, f, f), dtype=torch.float32, device=dev) for f in self.fm]
             for i, t in enumerate(loc_maps):

@@ -37,7 +37,7 @@ class SSD4Scale(EngineModule):
         self._engine_init(model=_lib.SSD4SCALE_VGG, size=size, num_classes=num_classes, c7_channel=c7_channel, bn=bn,
                           deform=deform, test_phase=(phase == 'test'))
 
-    def forward(self, x, ref_loc=list(), offset_list=list(), ret_loc=False, ret_off=False):
+    def forward(self, x, ref_loc=list(), offset_list=list(), ret_loc=False, ret_off=False, ref_event=None):
         if self.deform and not ref_loc:
             ref_loc = getattr(offset_list, "ref_loc", None)
             if ref_loc is None:
@@ -47,7 +47,8 @@ class SSD4Scale(EngineModule):
         r = self.engine_for(x).forward(x, want_offsets=bool(ret_off and self.deform),
                                           ref_loc=ref_loc if self.deform else None,
                                           want_loc_maps=bool(ret_loc and not self.deform),
-                                          reuse_offsets_token=getattr(offset_list, "token", None) if (self.deform and not ret_off) else None)
+                                          reuse_offsets_token=getattr(offset_list, "token", None) if (self.deform and not ret_off) else None,
+                                          ref_event=ref_event)
         conf = r["conf"] if self.phase == 'test' else r["conf"].view(x.size(0), -1, self.num_classes)
         out = [r["arm_loc"], conf]
         if ret_loc:

@@ -132,4 +132,4 @@ def test_bench_py_other_baseline_configs(config, batch):
     assert d["box_linf"] < 1.0 and "workload" in d["config"]
     if config == 5:
         assert abs(d["clips_per_s"] * 4 - d["value"]) / d["value"] < 1e-3
-        assert d["config"]["global_batch"] == batch * 4 and d["trn_mode"] == "batched"
+        assert d["config"]["global_batch"] == batch * 4 and d["trn_mode"] == "batched" and d["trn_static_net_overlapped"] is True

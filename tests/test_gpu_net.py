@@ -892,3 +892,46 @@ def test_trn_key_frame_broadcast_equals_the_frame_loop(model, targs):
         # a key-frame count that does not divide the batch is an argument error
         with pytest.raises(ValueError):
             temp(all_frames[:F * Bk - 1], ref_loc=maps)
+
+
+def test_trn_static_net_beside_the_temporal_trunk():
+    """tdrn_net_io.reserved[2]: the static net's forward on a SECOND stream while the temporal net's trunk runs on the caller's; the
+    temporal forward waits for the static net's event right before its first read of the loc maps.  Eager and as one captured
+    hipGraph (the static net on a one-stream plan: a forward that forks its own lanes from a stream which joined the capture by an
+    event takes hipStreamEndCapture down on ROCm 7.2): every output equals the serial order's, bit for bit, also when the static
+    net is made slow enough that a missing wait would read stale maps (a second, different key-frame batch in the same buffers)."""
+    stat, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, False), seed=0)
+    stat.set_plan_flags(_lib.PLAN_ONE_STREAM)
+    temp, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, True), seed=1)
+    for n in (stat, temp):
+        n.set_compute_dtype("bf16")
+    Bk, F = 2, 3
+    side, ev = torch.cuda.Stream(DEV), torch.cuda.Event()
+
+    def serial(frames):
+        s_loc, _, maps = stat(frames[0], ret_loc=True)
+        loc, conf = temp(frames.view(F * Bk, 3, 320, 320), ref_loc=maps)[:2]
+        return loc, conf, s_loc
+
+    def overlapped(frames):
+        main = torch.cuda.current_stream(DEV)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            s_loc, _, maps = stat(frames[0], ret_loc=True)
+            ev.record(side)
+        loc, conf = temp(frames.view(F * Bk, 3, 320, 320), ref_loc=maps, ref_event=ev)[:2]
+        main.wait_stream(side)
+        return loc, conf, s_loc
+
+    batches = [torch.from_numpy(synth.synth_frames(F * Bk, 320, seed=51 + k)).to(DEV).view(F, Bk, 3, 320, 320) for k in range(3)]
+    want = [[t.clone() for t in serial(b)] for b in batches]
+    for b, w in zip(batches, want):                                   # eager
+        got = overlapped(b)
+        torch.cuda.synchronize()
+        assert all(torch.equal(u, v) for u, v in zip(got, w))
+    from tdrn_amd.engine import GraphedCall                           # one captured graph, replayed on changing inputs
+    g = GraphedCall(overlapped, batches[0])
+    for b, w in zip(batches, want):
+        got = g(b)
+        torch.cuda.synchronize()
+        assert all(torch.equal(u, v) for u, v in zip(got, w))
