@@ -37,19 +37,38 @@ class TRNDriver(object):
         self.current_i += 1
         return dets
 
-    def clips(self, frames, scale=None):
+    def clips(self, frames, scale=None, side_stream=None):
         """Offline evaluation of whole intervals: `frames` (F, Bk, 3, S, S) = the F <= interval consecutive frames of Bk clips,
         FRAME-major ([0] = the key frames).  One static forward over the Bk key frames, ONE temporal forward over all F * Bk frames
         (tdrn_net_io.reserved[1]: frame i reads the offsets of key frame i % Bk) and one Detect call on the static anchors --
         the same detections, bit for bit, as `step` frame by frame (within an interval a frame depends on the key frame only
         through the cached offsets and anchors, evaluate_trn.py:452-462), at the throughput of one batch of F * Bk frames.
+        `side_stream` (a torch.cuda.Stream): the static net runs THERE, beside the temporal net's trunk, and the temporal forward
+        waits for its event right before its first read of the loc maps (tdrn_net_io.reserved[2]) -- the static net's launches over
+        a few key frames leave most of the chip idle.  (Inside a stream capture the static net needs its one-stream plan,
+        `set_plan_flags(PLAN_ONE_STREAM)`: see tests/test_gpu_net.py::test_trn_static_net_beside_the_temporal_trunk.)
         Returns the Detect output (F * Bk, C, top_k, 5), frame-major; the per-stream state of `step` is not touched."""
         if frames.dim() != 5 or frames.size(0) > self.interval:
             raise ValueError("frames must be (F <= interval, clips, 3, S, S), got %r" % (tuple(frames.shape),))
         F, Bk = int(frames.size(0)), int(frames.size(1))
-        static_out = list(self.static_net(frames[0], ret_loc=self.deform))
-        anchors = static_out[0] * self.loose
         allf = frames.reshape(F * Bk, *frames.shape[2:])
-        out = self.net(allf, ref_loc=static_out[2]) if self.deform else self.net(allf)
+        if side_stream is not None and self.deform:
+            import torch
+            main = torch.cuda.current_stream(frames.device)
+            if getattr(self, "_maps_ready", None) is None:
+                self._maps_ready = torch.cuda.Event()          # (one event for the driver's life: never destroyed inside a capture)
+            side_stream.wait_stream(main)
+            with torch.cuda.stream(side_stream):
+                static_out = list(self.static_net(frames[0], ret_loc=True))
+                anchors = static_out[0] * self.loose
+                self._maps_ready.record(side_stream)
+            out = self.net(allf, ref_loc=static_out[2], ref_event=self._maps_ready)
+            main.wait_stream(side_stream)
+            for t in [anchors] + list(static_out[2]):
+                t.record_stream(main)
+        else:
+            static_out = list(self.static_net(frames[0], ret_loc=self.deform))
+            anchors = static_out[0] * self.loose
+            out = self.net(allf, ref_loc=static_out[2]) if self.deform else self.net(allf)
         self.key_frames += Bk
         return self.detector.forward(out[0], out[1], self.priors, arm_loc_data=anchors.repeat(F, 1, 1), scale=scale)

@@ -534,6 +534,11 @@ def test_trn_driver_key_frame_protocol():
     for f in range(4):
         for c in range(2):
             assert torch.equal(got[f * 2 + c], want[c][f][0]), (f, c)
+    # ... with the static net on a second stream beside the temporal trunk: the same detections
+    side = torch.cuda.Stream(DEV)
+    again = drv.clips(two.transpose(0, 1).contiguous(), side_stream=side)
+    torch.cuda.synchronize()
+    assert torch.equal(again, got)
 
 
 @pytest.mark.parametrize("size,mh", [(192, False), (384, True)])
