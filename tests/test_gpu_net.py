@@ -872,8 +872,8 @@ def test_trn_key_frame_broadcast_equals_the_frame_loop(model, targs):
     those offsets, so every output is BIT-identical; so are the offsets handed out.  Also through the reuse token (a second batched
     forward with the offsets left in the workspace), and the argument checks."""
     for dtype in ("bf16", "fp32"):
-        stat, _ = _build(model, targs + (False,), seed=0)
-        temp, _ = _build(model, targs + (True,), seed=1)
+        stat, sd_s = _build(model, targs + (False,), seed=0)
+        temp, sd_t = _build(model, targs + (True,), seed=1)
         for n in (stat, temp):
             n.set_compute_dtype(dtype)
         Bk, F = (3, 4) if dtype == "bf16" else (2, 2)
@@ -897,6 +897,18 @@ def test_trn_key_frame_broadcast_equals_the_frame_loop(model, targs):
         # a key-frame count that does not divide the batch is an argument error
         with pytest.raises(ValueError):
             temp(all_frames[:F * Bk - 1], ref_loc=maps)
+        if dtype == "fp32" and model == "ssd4scale_vgg":
+            # ... and directly against the CPU oracle run the reference's way (evaluate_trn.py:452-462): key frame of clip 1 through
+            # the static and the temporal net, frame 1 of that clip with the cached offset_list
+            c = 1
+            xk = frames[0, c:c + 1].cpu().numpy()
+            _, _, r_maps = net_ref.ssd4scale_vgg_forward(sd_s, xk, 21, "test", True, False, ret_loc=True)
+            r0_loc, r0_conf, r_offs = net_ref.ssd4scale_vgg_forward(sd_t, xk, 21, "test", True, True, ref_loc=r_maps, ret_off=True)
+            r1_loc, r1_conf = net_ref.ssd4scale_vgg_forward(sd_t, frames[1, c:c + 1].cpu().numpy(), 21, "test", True, True, offset_list=r_offs)[:2]
+            conf = got[1].view(F * Bk, -1, 21)
+            np.testing.assert_allclose(got[0][c].cpu().numpy(), r0_loc.numpy()[0], atol=2e-3, rtol=0)
+            np.testing.assert_allclose(got[0][Bk + c].cpu().numpy(), r1_loc.numpy()[0], atol=2e-3, rtol=0)
+            np.testing.assert_allclose(conf[Bk + c].cpu().numpy(), r1_conf.numpy().reshape(-1, 21), atol=1e-3, rtol=0)
 
 
 def test_trn_static_net_beside_the_temporal_trunk():
