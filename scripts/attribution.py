@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--out", default="profiles/r04_attribution")
+    ap.add_argument("--reverse", action="store_true",
+                    help="the other direction: ops [0, s) run in the 16-bit type, ops [s, end) in fp32 on the 16-bit run's tensors -- "
+                         "the best ANY mixed plan with a 16-bit prefix could do (round 5)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     net0 = build_net("test", 320, 21, 1024, 1, True, True)
@@ -114,6 +117,9 @@ def main():
         r = e16.forward(x, out=out, first_op=s)
         torch.cuda.synchronize()
         return r
+
+    if args.reverse:
+        return reverse(args, e32, e16, ops16, x, B, pri, det, scale, r32, box32, det32)
 
     r16 = run_from(0)
     e0 = (boxes_of(r16, pri) - box32).abs().amax(-1)                           # (B, P): worst coordinate of every box
@@ -155,6 +161,50 @@ def main():
             f.write("| %s | %.4f | %.4f | %+.4f | %.2e | %+.2e | %d | %d / %d |\n" % (r_["first_16bit_stage"], r_["worst50_mean"], r_["worst50_max"], r_["stage_contribution_worst50_mean"],
                                                                                   r_["all_mean"], r_["stage_contribution_all_mean"], r_["boxes_over_1e3"], r_["detections_matched"], r_["detections_fp32"]))
     print("plain %s forward: detections matched %d / %d" % (args.dtype, m0, n_ref))
+
+
+def reverse(args, e32, e16, ops16, x, B, pri, det, scale, r32, box32, det32):
+    """16-bit prefix, fp32 suffix: what would a mixed plan buy whose LAST stages run exactly?"""
+    r16 = e16.forward(x, want_offsets=True)
+    torch.cuda.synchronize()
+    names16 = e16.tensor_infos()
+    t16 = {}
+    for o in ops16:
+        for t in (o["out"], o["pool"]):
+            if t >= 0 and names16[t][0]:
+                t16[t] = e16.read_tensor(t, B).clone()
+    e0 = (boxes_of(r16, pri) - box32).abs().amax(-1)
+    _, m0 = agreement(det32, det.forward(r16["odm_loc"], r16["conf"], pri, arm_loc_data=r16["arm_loc"], scale=scale))
+    boundaries = [i for i, o in enumerate(ops16) if o["kind"] in ("conv", "conv_transpose", "offset_conv", "deform_heads")]
+    first_deform = min(i for i, o in enumerate(ops16) if o["kind"] == "deform_heads")
+    boundaries = [b for b in boundaries if b <= first_deform and b > 0]
+    rows = [dict(first_fp32_stage="(none: plain %s)" % args.dtype, all_mean=float(e0.mean()), all_max=float(e0.max()),
+                 boxes_over_1e3=int((e0 > 1e-3).sum()), boxes_over_1e2=int((e0 > 1e-2).sum()), detections_matched=m0)]
+    names32 = e32.tensor_infos()
+    for s in boundaries:
+        out = {"arm_loc": r16["arm_loc"].clone(), "odm_loc": r16["odm_loc"].clone(), "conf": r16["conf"].clone()}
+        e32.workspace(B)
+        for o in ops16[:s]:
+            for t in (o["out"], o["pool"]):
+                if t >= 0 and names32[t][0] and t in t16:
+                    e32.write_tensor(t, t16[t])
+        r = e32.forward(x, out=out, first_op=s)
+        torch.cuda.synchronize()
+        e = (boxes_of(r, pri) - box32).abs().amax(-1)
+        _, m = agreement(det32, det.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale))
+        o = ops16[s]
+        name = "%s:%s" % (o["kind"], o["w"] or names16[o["in"]][0])
+        rows.append(dict(first_fp32_stage=name, all_mean=float(e.mean()), all_max=float(e.max()), boxes_over_1e3=int((e > 1e-3).sum()),
+                         boxes_over_1e2=int((e > 1e-2).sum()), detections_matched=m))
+        print("%3d %-36s all mean %.2e max %.3f, %5d boxes > 1e-3, %4d > 1e-2 | detections matched %d" % (
+            s, name, rows[-1]["all_mean"], rows[-1]["all_max"], rows[-1]["boxes_over_1e3"], rows[-1]["boxes_over_1e2"], m), flush=True)
+    with open(os.path.join(args.out, "reverse_%s.md" % args.dtype), "w") as f:
+        f.write("# %s prefix, fp32 suffix: box error left when ops [0, s) run in %s and ops [s, end) in fp32 on the %s run's tensors\n\n" % (args.dtype, args.dtype, args.dtype))
+        f.write("dualrefinedet_vggbn 320, %d frames, %d priors each; boxes in normalised image coordinates; detections of 32 000.\n" % (B, box32.shape[1]))
+        f.write("The upper bound of what ANY mixed plan with a 16-bit trunk can reach: the suffix is exact, its inputs carry the prefix's drift.\n\n")
+        f.write("| first fp32 stage | all boxes mean | max | boxes > 1e-3 | boxes > 1e-2 | detections matched |\n|---|---|---|---|---|---|\n")
+        for r_ in rows:
+            f.write("| %s | %.2e | %.4f | %d | %d | %d |\n" % (r_["first_fp32_stage"], r_["all_mean"], r_["all_max"], r_["boxes_over_1e3"], r_["boxes_over_1e2"], r_["detections_matched"]))
 
 
 if __name__ == "__main__":

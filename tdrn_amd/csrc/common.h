@@ -5,7 +5,23 @@
 
 #include "../../include/tdrn_hip.h"
 
+#include <cstdlib>
+
 namespace tdrn {
+
+// Ablation switches (TDRN_CONV_ABLATE, TDRN_PW_ABLATE: skip the loads / the MFMAs / the stores of a kernel) make a launch return
+// GARBAGE on purpose.  They exist only in developer builds (make EXTRA=-DTDRN_DEV_ABLATE OUT=... BUILD=..., scripts/dev/pw_ablate.sh):
+// in the product library a stray environment variable cannot poison a result.
+inline int dev_ablate_env(const char *name)
+{
+#ifdef TDRN_DEV_ABLATE
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;

@@ -861,7 +861,7 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     p.n_tiles = a.Npad / BN;
     p.items = p.m_tiles * p.n_tiles;
     static int ablate = -1;
-    if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+    if (ablate < 0) ablate = dev_ablate_env("TDRN_CONV_ABLATE");     // (developer builds only: common.h)
     p.ablate = ablate;
     p.fx = a.fuse_x; p.fw = a.fuse_w; p.fb = a.fuse_b; p.fS = a.H; p.fCout = a.fuse_cout;
     p.max_wgs = a.max_wgs > 0 ? (a.max_wgs / 8) * 8 : 0;

@@ -604,7 +604,7 @@ static int make_params(const ConvArgs &a, ConvParams &p)
     p.splits = (a.splitk > 1 && a.partial) ? a.splitk : 1;
     p.partial = (float *)a.partial;
     static int ablate = -1;
-    if (ablate < 0) { const char *e = getenv("TDRN_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+    if (ablate < 0) ablate = dev_ablate_env("TDRN_CONV_ABLATE");     // (developer builds only: common.h)
     p.ablate = ablate;
     return TDRN_OK;
 }

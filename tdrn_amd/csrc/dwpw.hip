@@ -783,7 +783,7 @@ int launch_pw1x1(const ConvArgs &a, hipStream_t s)
     // may depend on the batch)
     if (p.items < 192) return TDRN_E_UNSUPPORTED;
     static int ablate = -1;
-    if (ablate < 0) { const char *e = getenv("TDRN_PW_ABLATE"); ablate = e ? atoi(e) : 0; }
+    if (ablate < 0) ablate = dev_ablate_env("TDRN_PW_ABLATE");     // (developer builds only: common.h)
     p.ablate = ablate;
     static int nmajor = -1;
     if (nmajor < 0) { const char *e = getenv("TDRN_PW_NMAJOR"); nmajor = e ? atoi(e) : 0; }

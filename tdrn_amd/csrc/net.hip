@@ -1248,7 +1248,12 @@ struct tdrn_net {
             Bk = (int)kb;
         }
         if (reuse_offsets && offs_key_batch != Bk) return TDRN_E_STATE;
-        if (cfg.deform && !reuse_offsets) { offs_ws = ws; offs_batch = B; offs_key_batch = Bk; }
+        // The reuse state is valid only once the offset launches of THIS forward have been enqueued and the forward returned OK
+        // (an early error return, or a tdrn_net_forward_from that starts behind the offset ops, leaves it invalid: a later
+        // reserved[0] call then gets TDRN_E_STATE instead of sampling stale or uninitialised offsets)
+        int offset_ops_enqueued = 0, offset_ops_planned = 0;
+        if (cfg.deform && !reuse_offsets) { offs_ws = nullptr; offs_batch = 0; offs_key_batch = 0; }
+        for (const Op &d : ops) offset_ops_planned += d.kind == OP_OFFSET;
         for (size_t oi = 0; oi < ops.size(); ++oi) {
             const Op &o = ops[oi];
             bool skip = false;
@@ -1508,6 +1513,7 @@ struct tdrn_net {
                     break;
             }
             if (rc != TDRN_OK) return rc;
+            offset_ops_enqueued += o.kind == OP_OFFSET;
             if (lanes && o.out >= 0 && tensor_shared[o.out]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.out], s));
             if (lanes && o.pool_t >= 0 && tensor_shared[o.pool_t]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.pool_t], s));
             if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) {
@@ -1517,7 +1523,11 @@ struct tdrn_net {
                 evi += 2;
             }
         }
-        return join.run();
+        const int jrc = join.run();
+        if (jrc == TDRN_OK && cfg.deform && !reuse_offsets && offset_ops_planned > 0 && offset_ops_enqueued == offset_ops_planned) {
+            offs_ws = ws; offs_batch = B; offs_key_batch = Bk;
+        }
+        return jrc;
     }
 
     int check_status(unsigned *detail)

@@ -108,7 +108,29 @@ def pin_to_gpu_numa_node(local_rank, world, sysfs="/sys", apply=True):
             os.sched_setaffinity(0, cpus)
         except OSError as e:
             return {"pinned": False, "reason": str(e)}
-    return {"pinned": bool(apply), "cpus": len(cpus), "first_cpu": min(cpus), "how": how}
+    return {"pinned": bool(apply), "cpus": len(cpus), "first_cpu": min(cpus), "how": how,
+            "gpu_bdf_assumed": gpus[idx][0] if 0 <= idx < len(gpus) else None}
+
+
+def hip_device_bdf(device_index):
+    """PCI address of the HIP device (call AFTER the GPU is initialised): what pin_to_gpu_numa_node's sysfs-order guess is checked
+    against -- HIP's enumeration order may differ from the PCI address order, and then `numa_pin.how` would claim the wrong node."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:                                                    # (older torch: no PCI fields)
+        return None
+
+
+def verify_pin(pin, device_index):
+    """Adds the HIP-side PCI address to a pin_to_gpu_numa_node record and says whether the guess was right."""
+    if not isinstance(pin, dict):
+        return pin
+    pin = dict(pin)
+    pin["gpu_bdf_hip"] = hip_device_bdf(device_index)
+    a, b = pin.get("gpu_bdf_assumed"), pin["gpu_bdf_hip"]
+    pin["bdf_match"] = (a.lower() == b.lower()) if (a and b) else None
+    return pin
 
 
 def shard_slice(n, rank, world):
@@ -144,16 +166,23 @@ def gather_results(local, rank, world, dst=0):
     # take the same collective sequence and a mismatch raises on EVERY rank instead of hanging one side in a different collective.
     is_t = torch.is_tensor(local) and local.dim() >= 1            # (a 0-dim tensor travels as an object)
     DT = [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.int32, torch.int64, torch.uint8, torch.int8, torch.bool, torch.int16]
-    hdr = torch.zeros(12, dtype=torch.int64, device=ctl_dev)
+    # (built on the host in one go and moved once: twelve element writes into a device tensor are twelve tiny H2D copies under RCCL;
+    # kind 2 = "a tensor this function cannot carry": it travels in the header too, so that the rank concerned raises AFTER the
+    # all_gather, together with everybody else, instead of leaving the others inside the collective)
+    h_host = [0] * 12
     if is_t:
         if local.dim() > 8 or local.dtype not in DT:
-            raise ValueError("gather_results: unsupported tensor (dim %d, %s)" % (local.dim(), local.dtype))
-        hdr[0], hdr[1], hdr[2], hdr[3] = 1, local.dim(), DT.index(local.dtype), local.shape[0]
-        for i, d in enumerate(local.shape[1:]):
-            hdr[4 + i] = d
+            h_host[0], h_host[1] = 2, local.dim()
+        else:
+            h_host[:4] = [1, local.dim(), DT.index(local.dtype), local.shape[0]]
+            h_host[4:4 + local.dim() - 1] = [int(d) for d in local.shape[1:]]
+    hdr = torch.tensor(h_host, dtype=torch.int64).to(ctl_dev)
     hdrs = [torch.zeros_like(hdr) for _ in range(world)]
     dist.all_gather(hdrs, hdr)
     hdrs = [h.cpu().tolist() for h in hdrs]
+    if any(h[0] == 2 for h in hdrs):
+        raise ValueError("gather_results: unsupported tensor on ranks %r (more than 8 dimensions or a dtype outside %r)"
+                         % ([r for r, h in enumerate(hdrs) if h[0] == 2], [str(d) for d in DT]))
     kinds = {h[0] for h in hdrs}
     if len(kinds) != 1:
         raise ValueError("gather_results: ranks disagree on what they gather (tensor on ranks %r, object on the others); pass an "

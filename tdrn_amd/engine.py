@@ -17,6 +17,8 @@ class NetEngine(object):
                  multihead=False, deform=False, test_phase=True, dtype="fp32", use_refine=False, plan_flags=0):
         self.lib = _lib.lib()
         self.dtype_name = dtype
+        self._ctor = dict(model=model, size=size, num_classes=num_classes, c7_channel=c7_channel, def_groups=def_groups, bn=bn,
+                          multihead=multihead, deform=deform, test_phase=test_phase, dtype=dtype, use_refine=use_refine, plan_flags=plan_flags)
         cfg = NetConfig(model=model, size=size, num_classes=num_classes, c7_channel=c7_channel,
                         def_groups=def_groups, bn=int(bool(bn)), multihead=int(bool(multihead)),
                         deform=int(bool(deform)), test_phase=int(bool(test_phase)),
@@ -83,6 +85,13 @@ class NetEngine(object):
         self.weights, self.device = other.weights, other.device
         check(self.lib.tdrn_net_adopt_weights(self.handle))
 
+    def clone(self):
+        """A second handle of the same plan over the SAME packed blob, with its own workspace and side lanes: what a second
+        step in flight runs on (InFlight below, FrameStream with several engines)."""
+        e = NetEngine(**self._ctor)
+        e.share_weights(self)
+        return e
+
     def broadcast_weights(self, src=0):
         """One RCCL broadcast of the packed blob over xGMI; every other rank adopts it (no
         per-frame collective follows).  Call after load() on rank `src`, instead of load() elsewhere."""
@@ -143,11 +152,6 @@ class NetEngine(object):
             Bk = int(ref_loc[0].size(0))
             if not self.cfg.deform or Bk < 1 or B % Bk:
                 raise ValueError("ref_loc holds %d key frames for a batch of %d frames (needs a deform=True ssd4scale net and B %% Bk == 0)" % (Bk, B))
-        if want_offsets:
-            g18 = (8 if self.cfg.deform else self.cfg.def_groups) * 18
-            offsets = [torch.empty((Bk if self.cfg.deform else B, g18, f, f), dtype=torch.float32, device=dev) for f in self.fm]
-            for i, t in enumerate(offsets):
-                io.offsets[i] = t.data_ptr()
         # TRN temporal nets: the offsets computed by an earlier forward of THIS engine in the same workspace at the same batch are
         # reused when the caller presents the token that forward handed out (tdrn_net_io.reserved[0])
         reuse = (reuse_offsets_token is not None and reuse_offsets_token is getattr(self, "_offs_token", None)
@@ -160,6 +164,12 @@ class NetEngine(object):
             self._offs_token, self._offs_key = object(), (ws.data_ptr(), B, Bk)
         if Bk != B:
             io.reserved[1] = Bk
+        if want_offsets:
+            # (sized AFTER the reuse case has resolved Bk: a reused key-frame forward fills Bk samples, not B)
+            g18 = (8 if self.cfg.deform else self.cfg.def_groups) * 18
+            offsets = [torch.empty((Bk if self.cfg.deform else B, g18, f, f), dtype=torch.float32, device=dev) for f in self.fm]
+            for i, t in enumerate(offsets):
+                io.offsets[i] = t.data_ptr()
         if ref_loc is not None:
             for i, t in enumerate(ref_loc):
                 t = t.contiguous().float()
@@ -303,3 +313,62 @@ def _clone_tree(o):
     if isinstance(o, (list, tuple)):
         return type(o)(_clone_tree(v) for v in o)
     return o
+
+
+class InFlight(object):
+    """N whole steps in flight (round 5; the default schedule of bench.py and FrameStream is N = 2).
+
+    A step -- forward + Detect of one batch -- is a ~2-ms trunk of convolutions that fill the chip, followed by ~1 ms in which ~40
+    small dependent launches, the deformable heads and Detect leave most CUs idle.  With two pipelines (each its own engine handle,
+    workspace, HIP stream and hipGraph; ONE packed weight blob) the tail of step k runs under the trunk of step k + 1:
+    +3.5...4.5 % frames/s at batch 32, every pipeline's results bit-identical to the same step run alone (soak: 10 000 two-pipeline
+    and 9 000 three-pipeline replays, profiles/r05_attribution/soak*.txt).  Resident batch j is captured on pipeline j % N, so
+    n_batches should be a multiple of N.
+
+        fl = InFlight(lambda eng: (lambda x: detect(eng.forward(x)...)), engine, batches, n=2)
+        fl.launch(k)            # step k: replays batch k % len(batches) on its pipeline's stream; never blocks the host
+        fl.output(j)            # captured output of batch j (valid after fl.sync() or an event wait on fl.stream_of(j))
+    """
+
+    def __init__(self, make_step, engine, batches, n=2, graph=True):
+        dev = engine.device
+        self.n = max(1, int(n))
+        self.engines = [engine] + [engine.clone() for _ in range(self.n - 1)]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.n)]
+        self.steps = [make_step(e) for e in self.engines]
+        self.batches = list(batches)
+        self.graph = bool(graph)
+        self.calls = []
+        self.dev = dev
+        for j, xb in enumerate(self.batches):
+            p = j % self.n
+            if self.graph:
+                with torch.cuda.stream(self.streams[p]):
+                    self.calls.append(GraphedCall(self.steps[p], xb))
+                torch.cuda.synchronize(dev)
+            else:
+                self.calls.append(None)
+        self._eager_out = [None] * len(self.batches)
+
+    def launch(self, k):
+        j = k % len(self.batches)
+        p = j % self.n
+        with torch.cuda.stream(self.streams[p]):
+            if self.graph:
+                self.calls[j].graph.replay()
+            else:
+                self._eager_out[j] = self.steps[p](self.batches[j])
+        return j
+
+    def stream_of(self, j):
+        return self.streams[j % self.n]
+
+    def output(self, j):
+        return self.calls[j].outputs if self.graph else self._eager_out[j]
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
+    def check(self):
+        for e in self.engines:
+            e.check()

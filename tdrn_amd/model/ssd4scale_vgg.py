@@ -38,10 +38,16 @@ class SSD4Scale(EngineModule):
                           deform=deform, test_phase=(phase == 'test'))
 
     def forward(self, x, ref_loc=list(), offset_list=list(), ret_loc=False, ret_off=False, ref_event=None):
-        if self.deform and not ref_loc:
-            ref_loc = getattr(offset_list, "ref_loc", None)
-            if ref_loc is None:
-                raise ValueError("deform=True needs ref_loc (or an offset_list returned by this net)")
+        if self.deform and offset_list:
+            # the reference's precedence (ssd4scale_vgg.py:73-78): a non-empty offset_list wins over ref_loc.  Its offsets are a pure
+            # function of the loc maps it was computed from, which it carries along: THOSE are the source of truth, whether or
+            # not the engine's reuse token is still current (the token only decides whether they are recomputed or still there)
+            cached = getattr(offset_list, "ref_loc", None)
+            if cached is None:
+                raise ValueError("offset_list was not returned by this net (it carries no ref_loc to recompute the offsets from)")
+            ref_loc = cached
+        elif self.deform and not ref_loc:
+            raise ValueError("deform=True needs ref_loc (or an offset_list returned by this net)")
         # (the frames between two key frames hand back the offset_list of the key frame: its offsets are still in the engine's
         # workspace -- the token says so -- and are not recomputed, as in evaluate_trn.py:459-462)
         r = self.engine_for(x).forward(x, want_offsets=bool(ret_off and self.deform),

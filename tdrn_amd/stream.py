@@ -8,6 +8,8 @@ device (tdrn_preprocess), runs net + Detect, and only the (B, C, top_k, 5) detec
 Three queues, chained by events, `slots` (>= 3) buffers used cyclically:
     copy-in stream :  H2D of batch k+2's pinned frames          (waits for the step that last read that slot's device buffer)
     caller's stream:  hipGraph[slot] = tdrn_preprocess -> net (~60 launches on 4 lanes) -> Detect      (waits for its H2D)
+                      (round 5: given a LIST of engines, slot s runs on pipeline s % len(engines) -- the caller's stream and
+                      one extra stream per further engine: that many steps in flight, tdrn_amd/engine.py InFlight)
     copy-out stream:  D2H of batch k's detections               (waits for step k; step k + slots waits for it)
 Measured (bench.py `stream`, profiles/r03_experiments.md): 0.97 of the resident rate, given copy streams that do not share a
 hardware queue with a busy lane (see _pick_streams: chosen by a calibration at construction -- 16 stream pairs x 12 pipeline
@@ -43,35 +45,51 @@ class FrameStream(object):
     def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=3, calibrate=True):
         if slots < AHEAD + 1:
             raise ValueError("FrameStream needs at least %d slots (it copies %d batches ahead)" % (AHEAD + 1, AHEAD))
-        dev = engine.device
-        self.dev, self.B, self.slots = dev, batch, slots
+        # `engine`: one NetEngine, or a list of them (engine.clone(): own workspace and lanes, shared weights) = that many STEPS IN
+        # FLIGHT: slot s runs on pipeline s % len(engines), pipeline 0 on the caller's stream, the others on streams of their
+        # own, so the latency-bound tail of one step (small layers, deformable heads, Detect) runs under the next step's trunk
+        engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+        NP = len(engines)
+        if slots % NP:
+            raise ValueError("FrameStream: %d slots cannot be dealt evenly to %d pipelines" % (slots, NP))
+        import copy
+        detects = [detect] + [copy.copy(detect) for _ in range(NP - 1)]
+        for d in detects[1:]:
+            d._ws = None                                 # (a Detect owns its device workspace: one per pipeline)
+        dev = engines[0].device
+        self.dev, self.B, self.slots, self.pipelines = dev, batch, slots, NP
         H0, W0 = frame_hw
-        size = engine.cfg.size
+        size = engines[0].cfg.size
         scale = scale if scale is not None else [float(W0), float(H0), float(W0), float(H0)]
 
-        def one_step(u8):
-            x = base_transform(u8, size, mean)
-            r = engine.forward(x)
-            return detect.forward(r["odm_loc"], r["conf"], priors, arm_loc_data=r["arm_loc"], scale=scale)
-        self._fn = one_step
+        def make_step(eng, det):
+            def one_step(u8):
+                x = base_transform(u8, size, mean)
+                r = eng.forward(x)
+                return det.forward(r["odm_loc"], r["conf"], priors, arm_loc_data=r["arm_loc"], scale=scale)
+            return one_step
+        steps = [make_step(e, d) for e, d in zip(engines, detects)]
+        self._fn = steps[0]
+        self._extra_streams = [torch.cuda.Stream(dev) for _ in range(NP - 1)]
         self.host_in = [torch.empty((batch, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(slots)]
         self.dev_in = [torch.zeros((batch, H0, W0, 3), dtype=torch.uint8, device=dev) for _ in range(slots)]
         # lazily created resources (lanes, LDS attributes, workspaces) before any capture
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(2):
-                probe = one_step(self.dev_in[0])
+            for st in steps:
+                for _ in range(2):
+                    probe = st(self.dev_in[0])
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.host_out = [torch.empty(tuple(probe.shape), dtype=probe.dtype).pin_memory() for _ in range(slots)]
         self.graphs, self.dev_out = [], []
         for s in range(slots):
             g = torch.cuda.CUDAGraph()
-            # one private pool for all slots: the slots' steps run one after another on the caller's stream, so their
-            # intermediates may share memory (each slot's OUTPUT stays live and is never aliased)
-            with torch.cuda.graph(g, pool=self.graphs[0].pool() if self.graphs else None):
-                out = one_step(self.dev_in[s])
+            # one private pool per PIPELINE: a pipeline's steps run one after another on its stream, so their intermediates may
+            # share memory (each slot's OUTPUT stays live and is never aliased); steps of different pipelines run concurrently
+            with torch.cuda.graph(g, pool=self.graphs[s % NP].pool() if s >= NP else None):
+                out = steps[s % NP](self.dev_in[s])
             self.graphs.append(g)
             self.dev_out.append(out)
         self._in_stream = torch.cuda.Stream(dev)
@@ -155,10 +173,12 @@ class FrameStream(object):
         its detections.  Returns that step's slot; never blocks the host."""
         s = self._k % self.slots
         self._copy_in((self._k + AHEAD) % self.slots)
-        cur = torch.cuda.current_stream(self.dev)
-        cur.wait_event(self.ev_in[s])
-        self.graphs[s].replay()
-        self.ev_step[s].record(cur)
+        p = s % self.pipelines
+        cur = torch.cuda.current_stream(self.dev) if p == 0 else self._extra_streams[p - 1]
+        with torch.cuda.stream(cur):
+            cur.wait_event(self.ev_in[s])
+            self.graphs[s].replay()
+            self.ev_step[s].record(cur)
         with torch.cuda.stream(self._out_stream):
             self._out_stream.wait_event(self.ev_step[s])
             self.host_out[s].copy_(self.dev_out[s], non_blocking=True)

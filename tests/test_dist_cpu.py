@@ -51,19 +51,30 @@ def _worker(rank, world, port, n_frames, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [7, 8, 1])
-def test_two_rank_frame_sharding(n_frames):
+def _run_sharding(world, n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out = q.get(timeout=240)
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
     assert np.array_equal(out, np.arange(n_frames, dtype=np.float32) * 10 + 1.0)
+
+
+@pytest.mark.parametrize("n_frames", [7, 8, 1])
+def test_two_rank_frame_sharding(n_frames):
+    _run_sharding(2, n_frames)
+
+
+@pytest.mark.parametrize("n_frames", [256, 13, 5])
+def test_eight_rank_frame_sharding(n_frames):
+    """The driver's first multi-GPU run is N = 8: the same worker at world size 8 (gloo, CPU) -- 256 frames = bench.py's global
+    batch at 8 x 32, 13 = ragged shards, 5 = three ranks hold NOTHING (empty slices gather as empty tensors)."""
+    _run_sharding(8, n_frames)
 
 
 def test_shard_helpers_partition_exactly():
@@ -103,6 +114,13 @@ def _worker_mismatch(rank, world, port, q):
     sc = tdist.gather_results(torch.tensor(float(rank)), rank, world)
     if rank == 0:
         res.append([float(v) for v in sc])
+    # (4) ADVICE r04: a tensor the function cannot carry on ONE rank (a dtype outside its table) raises on EVERY rank, after the
+    # header exchange -- not on that rank alone before it, which left the others inside the all_gather
+    try:
+        tdist.gather_results(torch.zeros(2, 3, dtype=torch.complex64) if rank == 1 else torch.zeros(2, 3), rank, world)
+        res.append("no error")
+    except ValueError as e:
+        res.append("raised" if "unsupported tensor on ranks [1]" in str(e) else str(e))
     tdist.barrier()
     q.put((rank, res))
     dist.destroy_process_group()
@@ -122,6 +140,7 @@ def test_gather_results_mismatch_raises_on_every_rank():
         assert p.exitcode == 0
     assert got[0][:2] == ["raised", "raised"] and got[1][:2] == ["raised", "raised"]
     assert got[0][2] == [(2, 3), (0, 3)] and got[0][3] == [0.0, 1.0]
+    assert got[0][4] == "raised" and got[1][2] == "raised"
 
 
 def _fake_sysfs(root, gpus, nodes):

@@ -952,3 +952,72 @@ def test_trn_static_net_beside_the_temporal_trunk():
         got = g(b)
         torch.cuda.synchronize()
         assert all(torch.equal(u, v) for u, v in zip(got, w))
+
+
+def test_two_steps_in_flight_equal_one_at_a_time():
+    """Round 5, the default schedule of bench.py / FrameStream: two whole steps in flight (tdrn_amd.engine.InFlight -- pipeline p =
+    its own engine handle, workspace, stream and hipGraph over ONE weight blob).  Every batch's detections are, bit for bit, what
+    the same batch gives alone on one pipeline -- under concurrency (the chained split of conv3x3_pp polls flags while another
+    step's kernels hold CUs), turn after turn, and tdrn_net_check stays clean."""
+    from tdrn_amd.engine import InFlight
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    net.set_compute_dtype("bf16")
+    eng = net.engine(DEV)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    B, NB = 32, 4
+    xb = [torch.from_numpy(synth.synth_frames(B, 320, seed=300 + j)).to(DEV) for j in range(NB)]
+
+    def make_step(e):
+        d = Detect(21, 0, 200, 0.01, 0.45)
+
+        def one(x):
+            r = e.forward(x)
+            return d.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=[500.0, 375.0, 500.0, 375.0])
+        return one
+    alone = make_step(eng)
+    want = []
+    for j in range(NB):
+        want.append(alone(xb[j]).clone())
+        torch.cuda.synchronize()
+    for graph in (True, False):
+        fl = InFlight(make_step, eng, xb, n=2, graph=graph)
+        assert len(fl.engines) == 2 and fl.engines[1].weights.data_ptr() == eng.weights.data_ptr()
+        for turn in range(6):
+            for k in range(NB):
+                fl.launch(turn * NB + k)
+            if turn % 2:
+                fl.sync()
+                for j in range(NB):
+                    assert torch.equal(fl.output(j), want[j]), (graph, turn, j)
+        fl.sync()
+        fl.check()
+    assert (want[0][..., 0] > 0).any()
+
+
+def test_frame_stream_with_two_pipelines_equals_unstreamed():
+    """FrameStream given two engines (slot s on pipeline s % 2): same results as the unstreamed step, slot after slot."""
+    from tdrn_amd.stream import FrameStream
+    net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
+    net.set_compute_dtype("bf16")
+    eng = net.engine(DEV)
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    B, slots, n = 4, 4, 11
+    fs = FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots, calibrate=False)
+    assert fs.pipelines == 2
+    rng = np.random.RandomState(12)
+    feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)) for _ in range(n)]
+    fs.prime(feeds[:2])
+    results, pending = [], []
+    for k in range(n):
+        if k + 2 < n:
+            fs.pinned_in(fs.next_in()).copy_(feeds[k + 2])
+        pending.append(fs.run())
+        if len(pending) == 3:
+            results.append(fs.result(pending.pop(0)).clone())
+    while pending:
+        results.append(fs.result(pending.pop(0)).clone())
+    fs.drain()
+    for k, got in enumerate(results):
+        assert torch.equal(got, fs.eager(feeds[k].to(DEV)).cpu()), k
+    with pytest.raises(ValueError):
+        FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=3, calibrate=False)
