@@ -64,6 +64,14 @@ CONFIGS = {
 }
 # algorithmic GFLOP per frame and layer-boundary activation elements per frame (M)
 MOBILENET_GFLOP, MOBILENET_ACT_MELEMS = 22.340, 55.2
+NCLS = 21                                                        # --classes: VOC 21 (BASELINE's configs), VID 31 (evaluate_trn.py:526), COCO 81 (evaluate_coco.py:245)
+
+
+def head_gflop_delta(size, multihead=True, deform_taps=34, heads_per_level=1):
+    """algorithmic GFLOP per frame that the conf heads add per class beyond 21: 3 anchors x taps x 256 channels x 2 over the four
+    pyramid levels ((size/8)^2 (1 + 1/4 + 1/16 + 1/64) pixels); BASELINE.md's figures are quoted at 21 classes"""
+    px = (size / 8.0) ** 2 * (1 + 0.25 + 0.0625 + 0.015625)
+    return 2.0 * px * 3 * deform_taps * 256 * (NCLS - 21) / 1e9
 SSD4SCALE_VGG_GFLOP = 65.442
 
 
@@ -101,14 +109,14 @@ def parity_vs_oracle(size, dtypes, dev):
     from tdrn_amd.layers.box_utils import center_size, decode
     from tdrn_amd.model.dualrefinedet_vggbn import build_net
     from tdrn_amd.utils import synth
-    net = build_net("test", size, 21, 1024, 1, True, True)
+    net = build_net("test", size, NCLS, 1024, 1, True, True)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
     x = synth.synth_frames(1, size, seed=5)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     taps = {}
-    r_arm, _, r_odm, r_conf = net_ref.drn_vggbn_forward(sd, x, 21, True, True, taps=taps)
+    r_arm, _, r_odm, r_conf = net_ref.drn_vggbn_forward(sd, x, NCLS, True, True, taps=taps)
     cfg = dict(feature_maps=[size // 8, size // 16, size // 32, size // 64], min_dim=size, steps=[8, 16, 32, 64],
                min_sizes=[32, 64, 128, 256], max_sizes=[], aspect_ratios=[[2]] * 4, variance=[0.1, 0.2], clip=True,
                flip=True, name="bench")
@@ -136,7 +144,7 @@ def cpu_baseline(size, frames=2):
     from oracle import oracle as orc
     from tdrn_amd.model.dualrefinedet_vggbn import build_net
     from tdrn_amd.utils import synth
-    net = build_net("test", size, 21, 1024, 1, True, True)
+    net = build_net("test", size, NCLS, 1024, 1, True, True)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
     sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
     # torch's CPU convs peak at ~16 threads on the 256-core GPU host (measured: 8/16/32/64/128 threads
@@ -148,10 +156,10 @@ def cpu_baseline(size, frames=2):
                flip=True, name="bench")
     pri = orc.prior_box(cfg)
     x = synth.synth_frames(frames, size, seed=0)
-    net_ref.drn_vggbn_forward(sdt, x[:1], 21, True, True)          # warm-up (thread pools, page-in)
+    net_ref.drn_vggbn_forward(sdt, x[:1], NCLS, True, True)          # warm-up (thread pools, page-in)
     t0 = time.perf_counter()
     for i in range(frames):
-        arm, _, odm, conf = net_ref.drn_vggbn_forward(sdt, x[i:i + 1], 21, True, True)
+        arm, _, odm, conf = net_ref.drn_vggbn_forward(sdt, x[i:i + 1], NCLS, True, True)
         orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), (500, 375, 500, 375))
     dt = time.perf_counter() - t0
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
@@ -178,7 +186,7 @@ def detection_agreement(size, dtypes, dev, frames=8):
     from tdrn_amd.layers import Detect
     from tdrn_amd.model.dualrefinedet_vggbn import build_net
     from tdrn_amd.utils import synth
-    net = build_net("test", size, 21, 1024, 1, True, True)
+    net = build_net("test", size, NCLS, 1024, 1, True, True)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
@@ -191,7 +199,7 @@ def detection_agreement(size, dtypes, dev, frames=8):
     scale = (500.0, 375.0, 500.0, 375.0)
     ref = []
     for i in range(frames):
-        arm, _, odm, conf = net_ref.drn_vggbn_forward(sd, x[i:i + 1], 21, True, True)
+        arm, _, odm, conf = net_ref.drn_vggbn_forward(sd, x[i:i + 1], NCLS, True, True)
         ref.append(orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), scale)[0])     # (C, top_k, 5)
     pri_d = torch.from_numpy(pri).to(dev)
 
@@ -206,11 +214,11 @@ def detection_agreement(size, dtypes, dev, frames=8):
     for dt in dtypes:
         net.set_compute_dtype(dt)
         r = net.engine(dev).forward(torch.from_numpy(x).to(dev))
-        got = Detect(21, 0, 200, 0.01, 0.45).forward(r["odm_loc"], r["conf"], pri_d, arm_loc_data=r["arm_loc"],
+        got = Detect(NCLS, 0, 200, 0.01, 0.45).forward(r["odm_loc"], r["conf"], pri_d, arm_loc_data=r["arm_loc"],
                                                        scale=torch.tensor(scale)).cpu().numpy()
         n_ref = n_got = same_slot = matched = moved = 0
         for i in range(frames):
-            for c in range(1, 21):
+            for c in range(1, NCLS):
                 a, b = ref[i][c], got[i][c]
                 ka, kb = a[:, 0] > 0, b[:, 0] > 0
                 n_ref += int(ka.sum()); n_got += int(kb.sum()); same_slot += int((ka & kb).sum())
@@ -339,12 +347,12 @@ def main_other(args):
         # forward that forks its own stream lanes from a stream which itself joined the capture by an event takes
         # hipStreamEndCapture down on ROCm 7.2, scripts/dev/trn_overlap_probe.py)
         overlap = args.trn_mode == "batched" and bool(args.trn_overlap)
-        stat, sd_s, eng_s, bc1 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=False), 0,
+        stat, sd_s, eng_s, bc1 = make("ssd4scale_vgg", (S, NCLS), dict(c7_channel=1024, bn=False, deform=False), 0,
                                       _lib.PLAN_ONE_STREAM if overlap else 0)
-        temp, sd_t, eng_t, bc2 = make("ssd4scale_vgg", (S, 21), dict(c7_channel=1024, bn=False, deform=True), 1)
+        temp, sd_t, eng_t, bc2 = make("ssd4scale_vgg", (S, NCLS), dict(c7_channel=1024, bn=False, deform=True), 1)
         bcast_ms = bc1 + bc2
         FPC = 4                                                  # frames per clip = the key-frame interval
-        det = [Detect(21, 0, 200, 0.01, 0.45) for _ in range(FPC)]
+        det = [Detect(NCLS, 0, 200, 0.01, 0.45) for _ in range(FPC)]
         # a step's clips FRAME-major: (FPC, B, 3, S, S) -- [0] = the B key frames, .view(FPC * B, ...) = all frames, frame i of clip i % B
         xb = [torch.from_numpy(synth.synth_frames(B * FPC, S, seed=100 + rank + 1000 * j)).to(dev).view(FPC, B, 3, S, S) for j in range(NB)]
         batched = args.trn_mode == "batched"
@@ -387,8 +395,8 @@ def main_other(args):
         engines = [(eng_s, 1), (eng_t, 1 if batched else FPC)]
         name = "TRN ssd4scale_vgg static + temporal (deform, 8 groups)"
     else:
-        net, sd, eng, bcast_ms = make("dualrefinedet_mobilenet", (S, 21), dict(def_groups=1, multihead=True), 0)
-        det = Detect(21, 0, 200, 0.01, 0.45)
+        net, sd, eng, bcast_ms = make("dualrefinedet_mobilenet", (S, NCLS), dict(def_groups=1, multihead=True), 0)
+        det = Detect(NCLS, 0, 200, 0.01, 0.45)
         xb = [torch.from_numpy(synth.synth_frames(B, S, seed=100 + rank + 1000 * j)).to(dev) for j in range(NB)]
 
         def one_step(x):
@@ -408,7 +416,7 @@ def main_other(args):
             NF -= 1
 
         def make_step(e):
-            d = Detect(21, 0, 200, 0.01, 0.45)
+            d = Detect(NCLS, 0, 200, 0.01, 0.45)
 
             def step_of(x):
                 r = e.forward(x)
@@ -549,7 +557,7 @@ def main_other(args):
         NSL = 3
         while NSL % NF:
             NSL += 1
-        fs = FrameStream([eng] + [eng.clone() for _ in range(NF - 1)] if NF > 1 else eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NSL)
+        fs = FrameStream([eng] + [eng.clone() for _ in range(NF - 1)] if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL)
         rng = np.random.RandomState(7)
         for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -591,7 +599,7 @@ def main_other(args):
         "config": {"workload": "BASELINE config #%d: %s %dx%d, %s, %s per GPU, forward%s, synthetic VOC-shaped frames + synthetic weights" % (
                        args.config, name, S, S, args.dtype, (("%d clips x 4 frames (per step: 1 static forward over the %d key frames, ONE temporal forward over the %d frames with the key frames' offsets, one Detect call)" % (B, B, 4 * B)) if batched else
                                                        ("%d clips x 4 frames (per step: 1 static + 4 temporal forwards of %d frames + 4 Detect calls, frame by frame as evaluate_trn.py)" % (B, B))) if trn else "batch %d" % B,
-                       "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
+                       "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)") + ("" if NCLS == 21 else "; %d classes (not BASELINE's 21; the GFLOP figures stay the 21-class ones)" % NCLS),
                    "global_batch": world * frames_per_step, "parallelism": "%s-sharded x%d, no per-frame collective" % ("clip" if trn else "frame", world),
                    "launch": "hipGraph replay" if args.graph else "eager", "resident_batches": NB, "steps_in_flight": NF},
         "repetitions": {"n": len(reps), "reported": "median", "timed_steps_total": len(reps) * args.steps, "ms_per_step_min": round(reps[0] / args.steps * 1e3, 4), "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
@@ -618,9 +626,9 @@ def main_other(args):
         pr = pri.cpu().numpy()
         if trn:
             clip = synth.synth_frames(FPC, S, seed=5)
-            r_loc, r_conf, r_maps = net_ref.ssd4scale_vgg_forward(sd_s, clip[:1], 21, "test", False, False, ret_loc=True)
-            t_loc, t_conf, r_offs = net_ref.ssd4scale_vgg_forward(sd_t, clip[:1], 21, "test", False, True, ref_loc=r_maps, ret_off=True)
-            t1_loc, t1_conf = net_ref.ssd4scale_vgg_forward(sd_t, clip[1:2], 21, "test", False, True, offset_list=r_offs)[:2]
+            r_loc, r_conf, r_maps = net_ref.ssd4scale_vgg_forward(sd_s, clip[:1], NCLS, "test", False, False, ret_loc=True)
+            t_loc, t_conf, r_offs = net_ref.ssd4scale_vgg_forward(sd_t, clip[:1], NCLS, "test", False, True, ref_loc=r_maps, ret_off=True)
+            t1_loc, t1_conf = net_ref.ssd4scale_vgg_forward(sd_t, clip[1:2], NCLS, "test", False, True, offset_list=r_offs)[:2]
             xc = torch.from_numpy(clip).to(dev)
             g_loc, _, g_maps = stat(xc[:1], ret_loc=True)
             gt_loc, gt_conf, g_offs = temp(xc[:1], ref_loc=g_maps, ret_off=True)
@@ -633,7 +641,7 @@ def main_other(args):
             esc = np.abs(np.concatenate([gt_conf.cpu().numpy() - t_conf.numpy().reshape(gt_conf.shape), g1_conf.cpu().numpy() - t1_conf.numpy().reshape(g1_conf.shape)]))
         else:
             x1 = synth.synth_frames(1, S, seed=5)
-            r_arm, _, r_odm, r_conf = net_ref.drn_mobilenet_forward(sd, x1, 21, True)
+            r_arm, _, r_odm, r_conf = net_ref.drn_mobilenet_forward(sd, x1, NCLS, True)
             o = net(torch.from_numpy(x1).to(dev))
             rb = orc.decode(r_odm.numpy()[0], orc.center_size(orc.decode(r_arm.numpy()[0], pr)))
             gb = orc.decode(o[2].cpu().numpy()[0], orc.center_size(orc.decode(o[0].cpu().numpy()[0], pr)))
@@ -658,13 +666,13 @@ def main_other(args):
             sdt_t = {k: torch.from_numpy(v) for k, v in sd_t.items()}
             clip = synth.synth_frames(FPC, S, seed=0)
             while done < max(1, n // FPC):
-                r_loc, _, r_maps = net_ref.ssd4scale_vgg_forward(sdt_s, clip[:1], 21, "test", False, False, ret_loc=True)
+                r_loc, _, r_maps = net_ref.ssd4scale_vgg_forward(sdt_s, clip[:1], NCLS, "test", False, False, ret_loc=True)
                 offs = None
                 for f in range(FPC):
                     if f == 0:
-                        l, c, offs = net_ref.ssd4scale_vgg_forward(sdt_t, clip[:1], 21, "test", False, True, ref_loc=r_maps, ret_off=True)
+                        l, c, offs = net_ref.ssd4scale_vgg_forward(sdt_t, clip[:1], NCLS, "test", False, True, ref_loc=r_maps, ret_off=True)
                     else:
-                        l, c = net_ref.ssd4scale_vgg_forward(sdt_t, clip[f:f + 1], 21, "test", False, True, offset_list=offs)[:2]
+                        l, c = net_ref.ssd4scale_vgg_forward(sdt_t, clip[f:f + 1], NCLS, "test", False, True, offset_list=offs)[:2]
                     orc.detect(l.numpy(), c.numpy(), pr, r_loc.numpy(), (500, 375, 500, 375))
                 done += 1
             frames_done = done * FPC
@@ -672,7 +680,7 @@ def main_other(args):
             sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
             xs = synth.synth_frames(1, S, seed=0)
             while done < n:
-                arm, _, odm, conf = net_ref.drn_mobilenet_forward(sdt, xs, 21, True)
+                arm, _, odm, conf = net_ref.drn_mobilenet_forward(sdt, xs, NCLS, True)
                 orc.detect(odm.numpy(), conf.numpy(), pr, arm.numpy(), (500, 375, 500, 375))
                 done += 1
             frames_done = done
@@ -710,7 +718,10 @@ def main():
     ap.add_argument("--stream", type=int, default=1, help="1: also time the streamed mode (pinned uint8 frames H2D -> preprocess -> net -> Detect -> D2H, two slots in flight) and report it beside the resident figure")
     ap.add_argument("--per-op", action="store_true", help="print per-launch timings of one profiled forward to stderr")
     ap.add_argument("--cpu-frames", type=int, default=96)      # ~16 s of CPU work on the GPU box host
+    ap.add_argument("--classes", type=int, default=21, help="num_classes of the nets and of Detect: 21 = VOC (BASELINE's configs), 31 = VID (the TRN drivers), 81 = COCO")
     args = ap.parse_args()
+    global NCLS
+    NCLS = args.classes
     preset = CONFIGS[args.config]
     for k in ("size", "dtype", "batch"):
         if getattr(args, k) is None:
@@ -738,7 +749,7 @@ def main():
     torch.cuda.set_device(dev)
     build = _lib.lib().tdrn_version().decode()
 
-    net = build_net("test", args.size, 21, 1024, 1, True, True)
+    net = build_net("test", args.size, NCLS, 1024, 1, True, True)
     net.set_compute_dtype(args.dtype)
     if rank == 0:
         sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
@@ -757,7 +768,7 @@ def main():
     xb = [torch.from_numpy(synth.synth_frames(B, args.size, seed=100 + rank + 1000 * j)).to(dev) for j in range(NB)]
     x = xb[0]
     pri = PriorBox(mb_cfg["VOC_320" if args.size == 320 else "VOC_512_RefineDet"]).forward().to(dev)
-    det = Detect(21, 0, 200, 0.01, 0.45)
+    det = Detect(NCLS, 0, 200, 0.01, 0.45)
     scale = [500.0, 375.0, 500.0, 375.0]
 
     # optional intra-GPU concurrency: the batch is cut into --streams slices, each with its own engine
@@ -772,7 +783,7 @@ def main():
             e2.share_weights(eng)
             engines.append(e2)
             streams.append(torch.cuda.Stream(dev))
-            dets.append(Detect(21, 0, 200, 0.01, 0.45))
+            dets.append(Detect(NCLS, 0, 200, 0.01, 0.45))
 
     def eager_step(k):
         xs = list(torch.chunk(xb[k % NB], NS))
@@ -814,7 +825,7 @@ def main():
         from tdrn_amd.engine import InFlight
 
         def make_step(e):
-            d = Detect(21, 0, 200, 0.01, 0.45)
+            d = Detect(NCLS, 0, 200, 0.01, 0.45)
 
             def one_step(xin):
                 r = e.forward(xin)
@@ -922,7 +933,7 @@ def main():
         while NSL % NF:
             NSL += 1
         fs_engines = [eng] + [eng.clone() for _ in range(NF - 1)]                     # NF steps in flight here too (slot s on pipeline s % NF)
-        fs = FrameStream(fs_engines if NF > 1 else eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NSL)     # one pinned batch per slot: the slots' batches cycle
+        fs = FrameStream(fs_engines if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL)     # one pinned batch per slot: the slots' batches cycle
         rng = np.random.RandomState(7)
         for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -962,7 +973,7 @@ def main():
             print("bench.py: timing the %s mode" % dtm, file=sys.stderr, flush=True)
             net.set_compute_dtype(dtm)
             e2 = net.engine(dev)
-            st2 = in_flight_stepper(e2).launch if NF > 1 else make_stepper(e2, Detect(21, 0, 200, 0.01, 0.45))
+            st2 = in_flight_stepper(e2).launch if NF > 1 else make_stepper(e2, Detect(NCLS, 0, 200, 0.01, 0.45))
             k_steps = max(5, min(args.steps, 10 if dtm == "fp32" else args.steps))
             for k in range(3):
                 st2(k)
@@ -985,8 +996,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "dualrefinedet_vggbn %dx%d multihead, %s, batch %d per GPU, forward%s, synthetic "
-                                   "VOC-shaped frames + synthetic weights" %
-                                   (args.size, args.size, args.dtype, B, "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)"),
+                                   "VOC-shaped frames + synthetic weights%s" %
+                                   (args.size, args.size, args.dtype, B, "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)",
+                                    "" if NCLS == 21 else ", %d classes (not BASELINE's 21)" % NCLS),
                        "global_batch": world * B, "parallelism": "frame-sharded x%d, no per-frame collective" % world,
                        "launch": "hipGraph replay" if (args.graph and NS == 1) else "eager",
                        "resident_batches": NB,
@@ -997,7 +1009,7 @@ def main():
                             "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
             "fps_per_gpu": round(fps / world, 2),
             "forward_only_ms_per_step": round(fwd_ms, 4),
-            "forward_tflops": round(GFLOP_PER_FRAME.get(args.size, 0) * B / fwd_ms, 2),
+            "forward_tflops": round((GFLOP_PER_FRAME.get(args.size, 0) + head_gflop_delta(args.size)) * B / fwd_ms, 2),
             "build": build,
             "roofline": roofline,
             "kernels": kernels,

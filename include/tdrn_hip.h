@@ -358,6 +358,9 @@ typedef struct {
                           and the next op, that conv, is not a launch of its own); conv: 1 = computed by the depthwise op in front   */
     char w[48], b[48], bn[48], w2[48], b2[48];  /* state_dict prefixes ('' = none): weight / bias owner / BatchNorm; second source (merged 5x5+3x3 heads; offset2;
                           deformable heads: w = 3x3 loc, b = 3x3 conf, w2 = 5x5 loc, b2 = 5x5 conf)                             */
+    int y_groups;      /* deformable heads with y >= 0: output-column groups of <= 80 (12 loc + 3 * classes conf columns; 21 classes: 1,
+                          31: 2, 81: 4).  Tensor y holds one region per group, y channels / y_groups channels each; group g's region
+                          starts g * (y channels / y_groups) * H * W * B elements into the buffer and holds columns [80 g, 80 g + 80)   */
 } tdrn_op_info;
 TDRN_API int tdrn_net_op_count(const tdrn_net *net);
 TDRN_API int tdrn_net_op_info(const tdrn_net *net, int index, tdrn_op_info *out);

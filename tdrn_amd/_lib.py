@@ -51,7 +51,7 @@ class OpInfo(C.Structure):
                 ("ceil_mode", C.c_int), ("splitk", C.c_int), ("groups", C.c_int), ("out_kind", C.c_int), ("level", C.c_int),
                 ("n_branches", C.c_int), ("k2", C.c_int), ("pad2", C.c_int), ("off_c0", C.c_int * 2), ("y_tap_major", C.c_int),
                 ("fused_first", C.c_int), ("fused_dw", C.c_int), ("w", C.c_char * 48), ("b", C.c_char * 48), ("bn", C.c_char * 48), ("w2", C.c_char * 48),
-                ("b2", C.c_char * 48)]
+                ("b2", C.c_char * 48), ("y_groups", C.c_int)]
 
 
 OP_KINDS = ("first_conv", "conv", "conv_transpose", "depthwise", "maxpool", "l2norm", "offset_conv", "deform_heads", "other")

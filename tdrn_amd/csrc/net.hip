@@ -55,7 +55,9 @@ struct Op {
     std::string w, b, bn, w2, b2;                          // parameter names (w2/b2: second source)
     size_t w_off = 0, b_off = 0, w2_off = 0;               // blob offsets
     int y_t = -1, y_cols = 0;                              // deform, transform-then-sample plans: the Y tensor (per-tap partial outputs)
-    size_t wt_off = 0, bt_off = 0;                         // ... its 1x1 GEMM weights [y_cols][Cin] and zero bias
+    int y_groups = 1;                                      // ... output-column groups of <= 80 (12 + 3 * classes > 80: VID's 31 classes = 2, COCO's 81 = 4): one Y region,
+                                                           // one transform and one sampling launch per group (region g of the tensor: y_cols * H * W * B elements each)
+    size_t wt_off = 0, bt_off = 0;                         // ... its 1x1 GEMM weights [y_groups][y_cols][Cin] and zero bias
     double flops = 0, bytes = 0;                           // algorithmic, per sample
     int stat = 0;
     int lane = 0;                                          // HIP stream lane (0 = the caller's stream)
@@ -416,11 +418,12 @@ struct tdrn_net {
         {
             const char *e = getenv("TDRN_DEFORM_TS");
             const bool ts_on = e ? atoi(e) != 0 : !(cfg.plan_flags & TDRN_PLAN_NO_DEFORM_TS);
-            if (ts_on && cfg.dtype != TDRN_F32 && G == 1 && o.Cout <= 80 && (int)taps <= 34) {
+            if (ts_on && cfg.dtype != TDRN_F32 && G == 1 && (int)taps <= 34) {
+                o.y_groups = (o.Cout + 79) / 80;
                 o.y_cols = deform_sample_cols((int)taps);
-                o.y_t = T(o.y_cols, ti.H, ti.W);
-                o.wt_off = blob((size_t)o.y_cols * o.Cin * es);
-                o.bt_off = blob((size_t)o.y_cols * 4);
+                o.y_t = T(o.y_cols * o.y_groups, ti.H, ti.W);
+                o.wt_off = blob((size_t)o.y_groups * o.y_cols * o.Cin * es);
+                o.bt_off = blob((size_t)o.y_groups * o.y_cols * 4);
             }
         }
         push(o);
@@ -1062,7 +1065,7 @@ struct tdrn_net {
                                     const std::vector<float> &src = co < 12 ? *wl : *wc;
                                     const int cs = co < 12 ? co : co - 12;
                                     for (int ci = 0; ci < ti.C; ++ci)
-                                        put_elem(dt, ((size_t)deform_y_col(tap0 + t) + co) * o.Cin + ci, src[((size_t)cs * ti.C + ci) * taps + t]);
+                                        put_elem(dt, ((size_t)(co / 80) * o.y_cols + deform_y_col(tap0 + t) + co % 80) * o.Cin + ci, src[((size_t)cs * ti.C + ci) * taps + t]);
                                 }
                             tap0 += taps;
                         }
@@ -1436,7 +1439,11 @@ struct tdrn_net {
                             Bc = fit < Bc ? fit : Bc;
                         }
                         if (Bc < 1) { rc = TDRN_E_UNSUPPORTED; break; }
-                        for (int b0 = 0; b0 < B && rc == TDRN_OK; b0 += Bc) {
+                        // output columns in groups of 80 (deform.hip: a Y row is 80 columns): group g = columns [80 g, 80 g + 80) of
+                        // [12 loc ; 3 * classes conf], its own weight rows, Y region, transform and sampling launch
+                        const int n_groups = ops[ts_op[0]].y_groups;
+                        for (int b0 = 0; b0 < B && rc == TDRN_OK; b0 += Bc)
+                          for (int yg = 0; yg < n_groups && rc == TDRN_OK; ++yg) {
                             const int nb = B - b0 < Bc ? B - b0 : Bc;
                             DeformArgs ca[4];
                             YGemmProblem yq[4];
@@ -1460,14 +1467,18 @@ struct tdrn_net {
                                 c.out1 += (size_t)b0 * c.o1_bs;
                                 int taps = 0;
                                 for (int k = 0; k < c.n_branches; ++k) taps += c.br[k].kh * c.br[k].kw;
-                                void *ybuf = tptr(ws, d.y_t, B);
+                                if (d.y_groups != n_groups) { rc = TDRN_E_STATE; break; }
+                                void *ybuf = tptr(ws, d.y_t, B) + (size_t)yg * d.y_cols * c.H * c.W * es * B;
+                                const char *wty = wb + d.wt_off + (size_t)yg * d.y_cols * d.Cin * es;
+                                c.Cout = d.Cout - 80 * yg < 80 ? d.Cout - 80 * yg : 80;
+                                if (yg > 0) { c.split = 0; c.out1 += 80 * yg - 12; }     // (columns 12.. are conf columns: group g starts at conf column 80 g - 12)
                                 if (all_ygemm && ymulti) {       // all levels' transforms in ONE launch (below)
-                                    yq[n_yq++] = YGemmProblem{c.in, wb + d.wt_off, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, ts_tap_major ? taps : 0};
+                                    yq[n_yq++] = YGemmProblem{c.in, wty, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, ts_tap_major ? taps : 0};
                                 } else if (ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) {
-                                    rc = launch_ygemm(c.in, wb + d.wt_off, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, cfg.dtype, s, ts_tap_major ? taps : 0);
+                                    rc = launch_ygemm(c.in, wty, ybuf, (long long)nb * c.H * c.W, d.y_cols, d.y_cols, cfg.dtype, s, ts_tap_major ? taps : 0);
                                 } else {
                                     ConvArgs g;
-                                    g.in = c.in; g.w = wb + d.wt_off; g.bias = (const float *)(wb + d.bt_off); g.zero_page = wb;
+                                    g.in = c.in; g.w = wty; g.bias = (const float *)(wb + d.bt_off); g.zero_page = wb;
                                     g.B = nb; g.H = c.H; g.W = c.W; g.Cin = d.Cin; g.Ho = c.H; g.Wo = c.W; g.Cout = d.y_cols; g.Npad = d.y_cols;
                                     g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0; g.phases = 1; g.dtype = cfg.dtype;
                                     g.out = ybuf; g.kdisable = kdisable;
@@ -1478,7 +1489,7 @@ struct tdrn_net {
                             }
                             if (rc == TDRN_OK && n_yq > 0) rc = launch_ygemm_multi(yq, n_yq, cfg.dtype, s);
                             if (rc == TDRN_OK) rc = launch_deform_sample_multi(ca, ts_y, ts_cs, n_dargs, s, ts_tap_major);
-                        }
+                          }
                         n_dargs = 0;
                         break;
                     }
@@ -1696,6 +1707,7 @@ int tdrn_net_op_info(const tdrn_net *net, int index, tdrn_op_info *out)
         for (const Op &d : net->ops)
             if (d.kind == OP_DEFORM && d.y_t >= 0 && !ygemm_supported(d.Cin, d.y_cols, net->cfg.dtype)) all = false;
         out->y_tap_major = all ? 1 : 0;
+        out->y_groups = o.y_groups;
     }
     out->fused_first = (index == net->fuse_first) ? 1 : 0;
     out->fused_dw = o.fused_dw;

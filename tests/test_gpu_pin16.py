@@ -113,14 +113,18 @@ def _head_map(t, b, level, fm, per):
     return t[b, offs[level]:offs[level + 1]].reshape(f, f, per).permute(2, 0, 1)
 
 
-def check_stages(net, sd, x, dtype, images, skip_first_input=False):
-    """(b) + (c) for every launch of net's plan after net(x); `images`: batch rows that are recomputed on the CPU."""
+def check_stages(net, sd, x, dtype, images, skip_first_input=False, forward=None):
+    """(b) + (c) for every launch of net's plan after net(x); `images`: batch rows that are recomputed on the CPU.
+    `forward`: how to run the net when net(x) alone does not (the TRN temporal net needs ref_loc)."""
     B = x.shape[0]
-    outs = net(x)
+    outs = (forward or net)(x)
     torch.cuda.synchronize()
     eng = net._engine
     tinfo = eng.tensor_infos()
-    arm_loc, odm_loc, conf = outs[0], outs[2], outs[3]
+    if len(outs) >= 4:
+        arm_loc, odm_loc, conf = outs[0], outs[2], outs[3]
+    else:                                                    # ssd4scale nets: (loc, conf[, ...]); their heads write arm_loc / conf
+        arm_loc, odm_loc, conf = outs[0], outs[0], outs[1]
     fm = eng.fm
     cache = {}
 
@@ -257,14 +261,19 @@ def _check_transform_then_sample(eng, sd, op, tensor, odm_loc, conf, fm, B, imag
     taps = wt.shape[0]
     # ---- the device's Y, raw
     raw = tensor(op["y"])                                    # (B, ycols, H, W): an NHWC reading of the buffer
-    ycols = raw.shape[1]
-    flat = raw.permute(0, 2, 3, 1).reshape(-1)
-    if op["y_tap_major"]:
-        Yd = flat[:taps * M * 80].reshape(taps, M, 80)
-    else:
-        rows = flat.reshape(M, ycols)
-        Yd = torch.stack([rows[:, (t // 3) * 256 + (t % 3) * 80:(t // 3) * 256 + (t % 3) * 80 + 80] for t in range(taps)], 0)
-    Yd = Yd.double()
+    G = max(1, op["y_groups"])                               # column groups of 80 (12 + 3 * classes > 80): one buffer region each
+    ycols = raw.shape[1] // G
+    flat_all = raw.permute(0, 2, 3, 1).reshape(-1)
+    parts = []
+    for g in range(G):
+        flat = flat_all[g * ycols * M:(g + 1) * ycols * M]
+        if op["y_tap_major"]:
+            parts.append(flat[:taps * M * 80].reshape(taps, M, 80))
+        else:
+            rows = flat.reshape(M, ycols)
+            parts.append(torch.stack([rows[:, (t // 3) * 256 + (t % 3) * 80:(t // 3) * 256 + (t % 3) * 80 + 80] for t in range(taps)], 0))
+    Yd = torch.cat(parts, 2).double()                        # (taps, M, 80 G): column c of group g = output column 80 g + c
+    assert G == (ncol + 79) // 80, name
     assert float(Yd[:, :, ncol:].abs().max()) == 0.0, name + ": padding columns of Y are not zero"
     X = tensor(op["in"]).double()                            # (B, 256, H, W)
     off = tensor(op["off"])                                  # (B, Coff, H, W) fp32, exact
