@@ -160,7 +160,7 @@ def cpu_baseline(size, frames=2):
     t0 = time.perf_counter()
     for i in range(frames):
         arm, _, odm, conf = net_ref.drn_vggbn_forward(sdt, x[i:i + 1], NCLS, True, True)
-        orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), (500, 375, 500, 375))
+        orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), (500, 375, 500, 375), num_classes=NCLS)
     dt = time.perf_counter() - t0
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d frames of the same workload, batch 1, fp32 (oracle/: torch-CPU convs + C deformable "
@@ -200,7 +200,7 @@ def detection_agreement(size, dtypes, dev, frames=8):
     ref = []
     for i in range(frames):
         arm, _, odm, conf = net_ref.drn_vggbn_forward(sd, x[i:i + 1], NCLS, True, True)
-        ref.append(orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), scale)[0])     # (C, top_k, 5)
+        ref.append(orc.detect(odm.numpy(), conf.numpy(), pri, arm.numpy(), scale, num_classes=NCLS)[0])     # (C, top_k, 5)
     pri_d = torch.from_numpy(pri).to(dev)
 
     def iou(a, b):
@@ -673,7 +673,7 @@ def main_other(args):
                         l, c, offs = net_ref.ssd4scale_vgg_forward(sdt_t, clip[:1], NCLS, "test", False, True, ref_loc=r_maps, ret_off=True)
                     else:
                         l, c = net_ref.ssd4scale_vgg_forward(sdt_t, clip[f:f + 1], NCLS, "test", False, True, offset_list=offs)[:2]
-                    orc.detect(l.numpy(), c.numpy(), pr, r_loc.numpy(), (500, 375, 500, 375))
+                    orc.detect(l.numpy(), c.numpy(), pr, r_loc.numpy(), (500, 375, 500, 375), num_classes=NCLS)
                 done += 1
             frames_done = done * FPC
         else:
@@ -681,7 +681,7 @@ def main_other(args):
             xs = synth.synth_frames(1, S, seed=0)
             while done < n:
                 arm, _, odm, conf = net_ref.drn_mobilenet_forward(sdt, xs, NCLS, True)
-                orc.detect(odm.numpy(), conf.numpy(), pr, arm.numpy(), (500, 375, 500, 375))
+                orc.detect(odm.numpy(), conf.numpy(), pr, arm.numpy(), (500, 375, 500, 375), num_classes=NCLS)
                 done += 1
             frames_done = done
         dtc = time.perf_counter() - t0

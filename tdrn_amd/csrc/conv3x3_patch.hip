@@ -832,6 +832,10 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     const int mode = patch_conv_supported(a);
     if (!mode) return TDRN_E_UNSUPPORTED;
     if (out_pool && (mode < 0 || (a.H & 1) || (a.W & 1))) return TDRN_E_UNSUPPORTED;
+    if (ws_conv_supported(a)) {                           // conv3x3_ws.hip (Cin == 64): same arithmetic, same bits
+        const int rc = launch_conv3x3_ws(a, out_pool, s);
+        if (rc != TDRN_E_UNSUPPORTED) return rc;         // (it declines launches too small to fill the chip and fused launches it has no LDS for)
+    }
     if (!out_pool && pp_conv_supported(a)) {             // conv3x3_pp.hip: same arithmetic, same bits
         const int rc = launch_conv3x3_pp(a, out_pool, s);
         if (rc != TDRN_E_UNSUPPORTED) return rc;         // (it declines launches too small to fill the chip)

@@ -43,7 +43,8 @@ struct ConvArgs {
     void *sk_ws = nullptr;          // conv3x3_pp.hip: scratch of conv_pp_sk_bytes() for the chained split (one launch at a time), or null
     bool sk_flags_zero = false;     // the first 1024 bytes of sk_ws are zero on entry (every launch leaves them zero): no memset node
     // kernel-choice switches of this launch (tdrn_net_config.plan_flags TDRN_PLAN_NO_CONV_PP / _NO_PP_SK / _NO_CONV_PATCH):
-    // bit 0: not conv3x3_pp.hip, bit 1: no chained split, bit 2: neither 3x3 direct-conv kernel, bit 3: not pw1x1 (dwpw.hip).  Same output bits either way.
+    // bit 0: not conv3x3_pp.hip, bit 1: no chained split, bit 2: neither 3x3 direct-conv kernel, bit 3: not pw1x1 (dwpw.hip), bit 6: not
+    // conv3x3_ws.hip (TDRN_PLAN_NO_CONV_WS).  Same output bits either way.
     int kdisable = 0;
     // host-visible status words (pinned, device-mapped; tdrn_net_check): [0] <- 1 when a chained-split poll runs out,
     // [1] <- 1 when a poll of the chain launch does.  Null: a timed-out poll is not reported (dev harness only).
@@ -73,6 +74,12 @@ void conv_pp_force(int v);                      // dev harness: -1 = environment
 void conv_pp_sk_force(int v);                   // dev harness: the chained split ("stream-K") of conv3x3_pp.hip on / off
 int conv_pp_sk_enabled();                       // TDRN_CONV_PP_SK (default 1)
 size_t conv_pp_sk_bytes();
+// weight-stationary 3x3/s1/p1 kernel for the 16-bit Cin == 64 layers (conv3x3_ws.hip: the whole weight tile resident in LDS, the
+// activations in a ring of image rows, the first conv optionally computed by its producer waves); launch_conv3x3_patch hands those
+// layers over to it (TDRN_CONV_WS=0 / kdisable bit 6 keep the loader/consumer kernel).  Same output bits.
+int ws_conv_supported(const ConvArgs &a);
+int launch_conv3x3_ws(const ConvArgs &a, void *out_pool, hipStream_t s);
+void conv_ws_force(int v);                      // dev harness: -1 = environment, 0 / 1 = forced
 // rows of the packed weight matrix must be padded to a multiple of this
 int conv_n_pad(int cout);
 // channels of every NHWC activation tensor are padded to a multiple of this

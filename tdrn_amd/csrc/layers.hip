@@ -682,15 +682,16 @@ int launch_dwconv3(const void *in, const float *w, const float *bias, void *out,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row softmax over C (<= 64) classes: rows staged through LDS so that global traffic is
-// coalesced although a row is C*4 bytes; one thread owns one row.
+// Row softmax over C classes: rows staged through LDS so that global traffic is coalesced although a row is C*4 bytes; one thread
+// owns one row.  A workgroup takes `rb` rows (256 up to 59 classes -- VOC's 21, VID's 31 --, 128 up to 119 -- COCO's 81 --, 64 beyond):
+// rb * (C | 1) floats of LDS stay under 64 KiB.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                           long long R, int C)
+                                                           long long R, int C, int rb)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const long long r0 = (long long)blockIdx.x * 256;
-    const int rows = (int)((R - r0) < 256 ? (R - r0) : 256);
+    const long long r0 = (long long)blockIdx.x * rb;
+    const int rows = (int)((R - r0) < rb ? (R - r0) : rb);
     const int n = rows * C;
     const int ld = C | 1;                       // odd stride: conflict-free row-per-thread access
     for (int i = threadIdx.x; i < n; i += 256) sm[(i / C) * ld + (i % C)] = in[r0 * C + i];
@@ -713,10 +714,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restri
 
 int launch_softmax_rows(const float *in, float *out, long long R, int C, hipStream_t s)
 {
-    if (C < 1 || C > 64) return TDRN_E_UNSUPPORTED;
+    if (C < 1 || C > 255) return TDRN_E_UNSUPPORTED;
     if (R <= 0) return TDRN_OK;
-    dim3 grid((unsigned)((R + 255) / 256));
-    hipLaunchKernelGGL(softmax_rows_kernel, grid, dim3(256), 256 * (size_t)(C | 1) * sizeof(float), s, in, out, R, C);
+    const int rb = C <= 59 ? 256 : (C <= 119 ? 128 : 64);
+    dim3 grid((unsigned)((R + rb - 1) / rb));
+    hipLaunchKernelGGL(softmax_rows_kernel, grid, dim3(256), rb * (size_t)(C | 1) * sizeof(float), s, in, out, R, C, rb);
     return hip_status(hipGetLastError());
 }
 

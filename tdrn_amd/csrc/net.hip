@@ -678,7 +678,8 @@ struct tdrn_net {
         es = dtype_bytes(cfg.dtype);
         kdisable = ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PP) ? 1 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PP_SK) ? 2 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0) |
+                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
@@ -1504,7 +1505,24 @@ struct tdrn_net {
                                 TDRN_HIP_TRY(hipMemsetAsync(io->conf, 0, (size_t)B * P * C * sizeof(float), s));
                             }
                         }
-                        rc = launch_deform_multi(dargs, n_dargs, s, split);
+                        if (dargs[0].Npad <= 128) {
+                            rc = launch_deform_multi(dargs, n_dargs, s, split);
+                        } else {
+                            // the gather kernel holds at most 128 output columns per workgroup (deform.hip): COCO's 12 + 243 columns run as
+                            // column ranges of 128, each with its own weight rows and output columns (round 5; the C-ABI op does the same)
+                            for (int c0 = 0; c0 < dargs[0].Cout && rc == TDRN_OK; c0 += 128) {
+                                DeformArgs ga[4];
+                                for (int i = 0; i < n_dargs; ++i) {
+                                    ga[i] = dargs[i];
+                                    const int cols = dargs[i].Cout - c0 < 128 ? dargs[i].Cout - c0 : 128;
+                                    ga[i].Cout = cols; ga[i].Npad = deform_n_pad(cols);
+                                    for (int k = 0; k < ga[i].n_branches; ++k)
+                                        ga[i].br[k].w = (const char *)dargs[i].br[k].w + (size_t)c0 * dargs[i].br[k].kh * dargs[i].br[k].kw * dargs[i].Cin * es;
+                                    if (c0 > 0) { ga[i].out1 += c0 - dargs[i].split; ga[i].split = 0; }
+                                }
+                                rc = launch_deform_multi(ga, n_dargs, s, split);
+                            }
+                        }
                         n_dargs = 0;
                     }
                     break;

@@ -414,13 +414,16 @@ def test_kernel_choice_never_changes_a_bit(dtype):
     """(a) conv3x3_pp == conv3x3_patch and chained split == whole items, on the whole net (what csrc/dev/conv_check.hip shows
     layer by layer in the developer harness): the default plan against TDRN_PLAN_NO_CONV_PP and TDRN_PLAN_NO_PP_SK -- every
     output tensor torch.equal -- at 320 px batch 1 and 32 and at 512 px batch 3.  Not vacuous: the launch lists differ."""
-    cases = [(320, 1, 51), (320, 32, 52), (512, 3, 53)]
+    cases = [(320, 1, 51), (320, 32, 52), (512, 3, 53), (320, 7, 54)]      # (batch 7: ragged unit ranges of conv3x3_ws)
     for size, batch, seed in cases:
         args = (size,) + VGG[1][1:]
         base, _ = _build(VGG[0], args, dtype=dtype)
         x = torch.from_numpy(synth.synth_frames(batch, size, seed=seed)).to(DEV)
         want = _outputs(base, x)
-        for flags in (_lib.PLAN_NO_CONV_PP, _lib.PLAN_NO_PP_SK, _lib.PLAN_NO_CONV_PP | _lib.PLAN_NO_FUSE_FIRST):
+        # (round 5: + the weight-stationary conv3x3_ws.hip on conv1_2 / conv2_1 -- with the first conv fused into its producers, and
+        # from a materialised conv1_1 -- against conv3x3_patch.hip's loader / consumer kernel on the same layers)
+        for flags in (_lib.PLAN_NO_CONV_PP, _lib.PLAN_NO_PP_SK, _lib.PLAN_NO_CONV_PP | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_CONV_WS,
+                      _lib.PLAN_NO_CONV_WS | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_FUSE_FIRST):
             other, _ = _build(VGG[0], args, dtype=dtype, flags=flags)
             got = _outputs(other, x)
             assert len(got) == len(want)
