@@ -629,7 +629,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                         float v = acc[ci][pt][e];
                         if (TW == 32) v = fmaxf(v, acc[ci][1][e]);
                         else v = fmaxf(v, __shfl_xor(v, 16, 64));
-                        v = fmaxf(v, __shfl_xor(v, 1, 64));
+                        v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));     // lane ^ 1: a DPP quad permute, not an LDS round trip
                         acc[ci][pt][e] = v;
                     }
 #pragma unroll 1

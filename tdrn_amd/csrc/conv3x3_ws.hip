@@ -28,6 +28,7 @@
 // counter runs on across units.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -59,6 +60,9 @@ struct WsParams {
 #define WS_STAMP_DECL
 #define WS_STAMP(k) do { } while (0)
 #define WS_STAMP_FLUSH do { } while (0)
+#endif
+#ifndef TDRN_WS_PRIO
+#define TDRN_WS_PRIO 2            // 0: equal priorities, 1: producers at priority 2, 2: consumers at priority 2
 #endif
 #ifndef TDRN_WS_ABLATE
 #define TDRN_WS_ABLATE 0          // diagnostics: 1 = producers produce nothing, 2 = consumers skip reads + MFMAs, 4 = no epilogue
@@ -110,7 +114,8 @@ constexpr int kRawBytes = kRawPieces * 256;             // 4352 per buffer
 
 }  // namespace
 
-template <typename DT, bool FUSE>
+// MODE: 1 = full-resolution output, 2 = fused MaxPool2d(2,2) output, 3 = both (compile-time: the epilogue's ops sit inside the MFMA loop)
+template <typename DT, bool FUSE, int MODE>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
 {
     static_assert(sizeof(DT) == 2, "16-bit element types only");
@@ -119,10 +124,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
     constexpr int OFF_BIAS = OFF_RING + kRingBytes;     // 64 floats
     constexpr int OFF_FB = OFF_BIAS + 256;              // FUSE: the first conv's bias, 64 floats
     constexpr int OFF_RAW = OFF_FB + 256;               // FUSE: two raw halo tiles
-    constexpr int OFF_STG = OFF_RAW + (FUSE ? 2 * kRawBytes : 0);
-    constexpr int SROWS = FUSE ? 4 : 16;                // staging rows (pixels) per epilogue round and consumer wave
-    constexpr int SSTRIDE = 128 + 16;
-    constexpr int LDS = OFF_STG + 4 * SROWS * SSTRIDE;
+    constexpr int LDS = OFF_RAW + (FUSE ? 2 * kRawBytes : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
 
@@ -226,52 +228,83 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
                 }
             }
         };
-        // FUSE: the first conv of 32 patch pixels (slice sl of the batch, row-major over nrows x 34) -> ring rows
-        auto first_conv_slice = [&](const Batch &bt, int sl, int buf) {
+        // FUSE: the first conv of NS slices of 32 patch pixels (slices lw, lw + 4, ... of the batch, row-major over nrows x 34) -> ring
+        // rows.  The slices of a wave are processed TOGETHER, phase by phase (all raw reads, all MFMAs, all conversions and ring
+        // writes): a producer wave is alone on its SIMD beside a consumer that multiplies, so nothing else hides its LDS and
+        // matrix-pipe latencies (one slice at a time: ~2950 cycles per slice, the producers were the critical path of the launch).
+        // The accumulators start at the bias, held in registers for the whole launch.
+        // (ReLU on the packed pair as a signed 16-bit maximum with 0, see the consumers' pack_relu: exact for finite values)
+        typedef short ws_s2p __attribute__((ext_vector_type(2)));
+        auto fc_relu = [&](float a, float b) -> unsigned {
+            return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ws_s2p, pack2<DT>(a, b)), ws_s2p{0, 0}));
+        };
+        [[maybe_unused]] f32x16 fbias[2];
+        auto load_first_bias = [&]() {
             if constexpr (FUSE) {
-                const int pq = sl * 32 + r32;
-                const bool valid = pq < bt.nrows * kRingCols;
-                const int prow = pq / kRingCols, pcol = pq - prow * kRingCols;
-                // outside the frame the NEXT conv pads with zeros (not with the first conv evaluated out there)
-                const bool inimg = valid && (unsigned)(bt.yf + prow) < (unsigned)p.fS && (unsigned)(bt.x0 - 1 + pcol) < (unsigned)p.fS;
-                const float *raw = (const float *)(smem + OFF_RAW + buf * kRawBytes);
                 const float *b1 = (const float *)(smem + OFF_FB);
-                const int porg = valid ? prow * kRawCols + pcol : 0;
-                float xv[16];
-#pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2) xv[s2] = raw[porg + koff1[s2]];
-                f32x16 a1[2];
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bv = *(const f32x4 *)(b1 + ci * 32 + 8 * g + 4 * hh);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) a1[ci][4 * g + j] = bv[j];
+                        for (int j = 0; j < 4; ++j) fbias[ci][4 * g + j] = bv[j];
+                    }
+            }
+        };
+        auto first_conv_slices = [&](const Batch &bt, auto nsc, int buf) {
+            if constexpr (FUSE) {
+                constexpr int NS = decltype(nsc)::value;
+                const float *raw = (const float *)(smem + OFF_RAW + buf * kRawBytes);
+                float xv[NS][16];
+                int pqs[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int pq = (lw + 4 * i) * 32 + r32;
+                    pqs[i] = pq;
+                    const bool valid = pq < bt.nrows * kRingCols;
+                    const int prow = pq / kRingCols, pcol = pq - prow * kRingCols;
+                    const int porg = valid ? prow * kRawCols + pcol : 0;
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) xv[i][s2] = raw[porg + koff1[s2]];
+                }
+                f32x16 a1[NS][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        u32x4 xq;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) xq[jj] = pack2<DT>(xv[i][8 * ks + 2 * jj], xv[i][8 * ks + 2 * jj + 1]);
+#pragma unroll
+                        for (int ci = 0; ci < 2; ++ci) {
+                            if (ks == 0) a1[i][ci] = fbias[ci];
+                            MmaW<DT>::run(wq1[ci][ks], xq, a1[i][ci]);
+                        }
                     }
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 xq;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) xq[jj] = pack2<DT>(xv[8 * ks + 2 * jj], xv[8 * ks + 2 * jj + 1]);
-#pragma unroll
-                    for (int ci = 0; ci < 2; ++ci) MmaW<DT>::run(wq1[ci][ks], xq, a1[ci]);
-                }
-                if (valid) {
+                for (int i = 0; i < NS; ++i) {
+                    const int pq = pqs[i];
+                    const bool valid = pq < bt.nrows * kRingCols;
+                    const int prow = pq / kRingCols, pcol = pq - prow * kRingCols;
+                    // outside the frame the NEXT conv pads with zeros (not with the first conv evaluated out there)
+                    const bool inimg = valid && (unsigned)(bt.yf + prow) < (unsigned)p.fS && (unsigned)(bt.x0 - 1 + pcol) < (unsigned)p.fS;
                     int sl_ = bt.s0 + prow;
                     sl_ = sl_ >= kRingRows ? sl_ - kRingRows : sl_;
                     const int q = sl_ * kRingCols + pcol;
                     char *row = smem + OFF_RING + q * 128 + 8 * hh;
                     const int sw = (q >> 1) & 7;
+                    const unsigned keep = inimg ? 0xFFFFFFFFu : 0u;      // (one AND per packed pair; no second code path for border slices)
+                    if (valid) {
 #pragma unroll
-                    for (int ci = 0; ci < 2; ++ci)
+                        for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            float q4[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) q4[j] = inimg ? fmaxf(a1[ci][4 * g + j], 0.f) : 0.f;
-                            *(uint2 *)(row + (((4 * ci + g) ^ sw) << 4)) = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
-                        }
+                            for (int g = 0; g < 4; ++g) {
+                                const unsigned w0 = fc_relu(a1[i][ci][4 * g], a1[i][ci][4 * g + 1]) & keep;
+                                const unsigned w1 = fc_relu(a1[i][ci][4 * g + 2], a1[i][ci][4 * g + 3]) & keep;
+                                *(uint2 *)(row + (((4 * ci + g) ^ sw) << 4)) = make_uint2(w0, w1);
+                            }
+                    }
                 }
             }
         };
@@ -317,6 +350,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
         write_first_bias();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // (b) the first conv's bias is in place
+        load_first_bias();
+        if (TDRN_WS_PRIO == 1) __builtin_amdgcn_s_setprio(2);
         int n = 0, prev_nt = un.nt;
         WS_STAMP_DECL
         for (int u = u0; u < u1; ++u) {
@@ -336,8 +371,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
                 }
                 if constexpr (!(TDRN_WS_ABLATE & 1)) {
                     if constexpr (FUSE) {
-                        const int nsl = (bt.nrows * kRingCols + 31) / 32;
-                        for (int sl = lw; sl < nsl; sl += 4) first_conv_slice(bt, sl, n & 1);
+                        // 8 rows: 272 pixels = 9 slices (wave 0 three, the others two); 2 rows: 68 pixels = 3 slices (waves 0 - 2 one each)
+                        if (bt.nrows == 8) {
+                            if (lw == 0) first_conv_slices(bt, std::integral_constant<int, 3>{}, n & 1);
+                            else first_conv_slices(bt, std::integral_constant<int, 2>{}, n & 1);
+                        } else if (lw < 3) {
+                            first_conv_slices(bt, std::integral_constant<int, 1>{}, n & 1);
+                        }
                     } else {
                         dma_rows(bt);
                     }
@@ -359,61 +399,161 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
 
     // ======================================= CONSUMERS =======================================
     const int cw = wave;                                // tile rows 2 cw, 2 cw + 1 (pixel fragment pt = row 2 cw + pt, lane r32 = x)
-    char *stg = smem + OFF_STG + cw * SROWS * SSTRIDE;
     f32x16 acc[2][2];                                   // [cout tile ci][pixel fragment pt]
     // weight fragment bases (tile-invariant): row ci*32 + r32 of a tap, 16-byte chunk (2 kk + hh) ^ ((r32 >> 1) & 7)
     unsigned wa[2];
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) wa[ci] = (unsigned)(OFF_W + (ci * 32 + r32) * 128 + ((hh ^ ((r32 >> 1) & 7)) << 4));
+    // ReLU on the PACKED 16-bit pair as a signed 16-bit maximum with 0 (v_pk_max_i16: a negative value -- and -0 -- has its sign bit set,
+    // i.e. is a negative integer; finite values come out exactly as max(v, 0) before the conversion does); no ReLU: maximum with -32768
+    typedef short ws_s2 __attribute__((ext_vector_type(2)));
+    const ws_s2 relu_lo = p.relu ? ws_s2{0, 0} : ws_s2{(short)-32768, (short)-32768};
+    auto pack_relu = [&](float a, float b) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ws_s2, pack2<DT>(a, b)), relu_lo));
+    };
+
+    // ---- epilogue in two halves ------------------------------------------------------------------------------------------------
+    // A lane holds, per pixel fragment, 8 groups (ci, g) of 4 couts: group c = 4 ci + g is the 16-byte chunk c of the pixel's 128-byte
+    // row, of which lane r32 (hh = 0) has the first 8 bytes and lane r32 + 32 the second.  (1) Right behind a tile's last MFMAs the
+    // accumulators are CONVERTED into packed 16-bit registers (full-resolution rows: 2 x 8 groups; pooled: the fused MaxPool2d(2,2) on
+    // the raw accumulators first -- max commutes with the monotonic bias + ReLU; the partner row is my other pixel fragment, the partner
+    // column lane ^ 1, a DPP quad permute -- then 8 groups), and the accumulators are free for the next tile.  (2) The STORES run as
+    // independent ops between the MFMA groups of the next tile's first steps: v_permlane32_swap on a PAIR of chunks (c, c + 1) gives the
+    // lower lane all 16 bytes of chunk c and the upper lane all of chunk c + 1 (cdna_hip_programming.md T21), one dwordx4 store per pair,
+    // 32 contiguous bytes per pixel and instruction, no LDS round trip.  Pooled rows: both lanes of a column pair hold the same maxima and
+    // store the same bytes to the same pooled pixel.  (A consumer wave is alone on its SIMD beside a producer: the first version's epilogue
+    // -- LDS staging rounds, ds_bpermute -- ran on its own for 4150 of a tile's 9700 cycles.)
+    uint2 pk_out[MODE & 1 ? 2 : 1][8], pk_pool[8];     // packed groups of the finished tile: [pixel fragment][chunk c]
+    char *pd_out[2] = {nullptr, nullptr}, *pd_pool = nullptr;      // ... and where its rows go (null: nothing pending)
+    auto convert = [&]() {
+        if constexpr (TDRN_WS_ABLATE & 4) return;
+        if constexpr (MODE & 1) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        pk_out[pt][4 * ci + g] = make_uint2(pack_relu(acc[ci][pt][4 * g], acc[ci][pt][4 * g + 1]), pack_relu(acc[ci][pt][4 * g + 2], acc[ci][pt][4 * g + 3]));
+        }
+        if constexpr (MODE & 2) {
+            // MaxPool2d(2,2) + ReLU on the PACKED values, as signed 16-bit maxima: rounding to 16 bits is monotonic, so it commutes with the
+            // maximum; after max(., 0) every candidate is a non-negative 16-bit float, whose bit patterns order like integers -- and
+            // max(max(a, b), 0) = max(max(a, 0), max(b, 0)).  (Pooled layers always carry a ReLU: the launcher declines otherwise.)
+            // Only compiler-visible instructions here: the accumulators come straight out of the MFMAs, and hipcc pads the MFMA -> VALU
+            // and VALU -> DPP wait states for its own instructions only, not around inline asm.
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned w2[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const ws_s2 zero = {0, 0};
+                        const ws_s2 u0 = __builtin_bit_cast(ws_s2, pack2<DT>(acc[ci][0][4 * g + 2 * h], acc[ci][0][4 * g + 2 * h + 1]));
+                        const ws_s2 u1 = __builtin_bit_cast(ws_s2, pack2<DT>(acc[ci][1][4 * g + 2 * h], acc[ci][1][4 * g + 2 * h + 1]));
+                        const ws_s2 m = __builtin_elementwise_max(__builtin_elementwise_max(u0, u1), zero);
+                        const ws_s2 nb = __builtin_bit_cast(ws_s2, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true));
+                        w2[h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(m, nb));
+                    }
+                    pk_pool[4 * ci + g] = make_uint2(w2[0], w2[1]);
+                }
+        }
+    };
+    // op 0-7: full-resolution rows (pixel fragment op / 4, chunk pair op % 4); ops 8-9: pooled rows -- both lanes of a column pair hold the
+    // same maxima, so the even lane stores pair 2 (op - 8) and the odd lane pair 2 (op - 8) + 1 of the same pooled pixel: TWO stores per
+    // tile and wave instead of four with the odd lanes idle (a store costs the issuing wave ~150 cycles: 8 % of the launch with four)
+    auto store_op = [&](auto opc) {
+        constexpr int OP = decltype(opc)::value;
+        if constexpr (TDRN_WS_ABLATE & 4) return;
+        uint2 a, b;
+        char *dst;
+        if constexpr (OP < 8) {
+            constexpr int pr = OP & 3, pt = (MODE & 1) ? (OP >> 2) : 0;
+            a = pk_out[pt][2 * pr]; b = pk_out[pt][2 * pr + 1];
+            dst = pd_out[pt] + pr * 32 + hh * 16;
+        } else {
+            constexpr int j = OP - 8;
+            const bool odd = r32 & 1;
+            a.x = odd ? pk_pool[4 * j + 2].x : pk_pool[4 * j].x;     a.y = odd ? pk_pool[4 * j + 2].y : pk_pool[4 * j].y;
+            b.x = odd ? pk_pool[4 * j + 3].x : pk_pool[4 * j + 1].x; b.y = odd ? pk_pool[4 * j + 3].y : pk_pool[4 * j + 1].y;
+            dst = pd_pool + (2 * j + (odd ? 1 : 0)) * 32 + hh * 16;
+        }
+        auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+        auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+        if constexpr (TDRN_WS_ABLATE & 8) {             // (diagnostics: everything but the store instruction itself; p.B < 0 never holds)
+            if (p.B < 0) *(u32x4 *)dst = u32x4{rx[0], ry[0], rx[1], ry[1]};
+        } else {
+            *(u32x4 *)dst = u32x4{rx[0], ry[0], rx[1], ry[1]};
+        }
+    };
+    constexpr int NOPS = (MODE & 1 ? 8 : 0) + (MODE & 2 ? 2 : 0);
+    auto op_of = [](int i) constexpr -> int { return (MODE & 1) ? i : 8 + i; };      // i-th op of this MODE
+    auto flush = [&]() {
+        if (!pd_pool && !pd_out[0]) return;
+        store_op(std::integral_constant<int, op_of(0)>{}); store_op(std::integral_constant<int, op_of(1)>{});
+        if constexpr (NOPS > 2) {
+            store_op(std::integral_constant<int, op_of(2)>{}); store_op(std::integral_constant<int, op_of(3)>{});
+            store_op(std::integral_constant<int, op_of(4)>{}); store_op(std::integral_constant<int, op_of(5)>{});
+            store_op(std::integral_constant<int, op_of(6)>{}); store_op(std::integral_constant<int, op_of(7)>{});
+        }
+    };
 
     WS_STAMP_DECL
-    auto tile = [&](const Unit &un, int k, int us0) {
-        WS_STAMP(3);                                    // between tiles (periods without a tile, unit bookkeeping)
-        // ring slots of tile rows 2 cw .. 2 cw + 3 (rel rows 8k + 2cw + i), and the fragment base address of (row i, column shift kx)
-        unsigned pa[4][3];
-        {
-            int s = (us0 + 8 * k + 2 * cw) % kRingRows;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int q = s * kRingCols + r32 + kx;
-                    pa[i][kx] = (unsigned)(OFF_RING + q * 128 + ((hh ^ ((q >> 1) & 7)) << 4));
-                }
-                s = s + 1 == kRingRows ? 0 : s + 1;
-            }
-        }
-        // accumulators start at the bias
+    // the bias as the C operand of a tile's first MFMAs (two accumulator tiles' worth of registers, reloaded with the weights)
+    f32x16 cbias[2];
+    auto load_cbias = [&]() {
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *(const f32x4 *)(smem + OFF_BIAS + (ci * 32 + 8 * g + 4 * hh) * 4);
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ci][pt][4 * g + j] = bv[j];
+                for (int j = 0; j < 4; ++j) cbias[ci][4 * g + j] = bv[j];
             }
-        // 36 steps (tap-major, 4 K-slices per tap) of 4 reads + 4 MFMAs; fragments two steps ahead in registers
-        u32x4 wf[3][2], pf[3][2];
-        auto LD = [&](int s, int set) {
-            const int tap = s >> 2, kk = s & 3, ky = tap / 3, kx = tap - 3 * ky;
-            const unsigned kxor = (unsigned)(kk << 5);
+    };
+    // fragment base addresses of a tile whose first row (of mine) sits in ring slot s: (row i of 4, column shift kx)
+    unsigned pa[4][3];
+    auto tile_addresses = [&](int s) {
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci) wf[set][ci] = *(const u32x4 *)(smem + ((wa[ci] ^ kxor) + tap * 8192));
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) pf[set][pt] = *(const u32x4 *)(smem + (pa[pt + ky][kx] ^ kxor));
-        };
-        auto MMA = [&](int set) {
+            for (int kx = 0; kx < 3; ++kx) {
+                const int q = s * kRingCols + r32 + kx;
+                pa[i][kx] = (unsigned)(OFF_RING + q * 128 + ((hh ^ ((q >> 1) & 7)) << 4));
+            }
+            s = s + 1 == kRingRows ? 0 : s + 1;
+        }
+    };
+    u32x4 wf[3][2], pf[3][2];                           // operand fragments, two steps ahead of their MFMAs
+    auto LD = [&](int s, int set) {
+        const int tap = s >> 2, kk = s & 3, ky = tap / 3, kx = tap - 3 * ky;
+        const unsigned kxor = (unsigned)(kk << 5);
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
+        for (int ci = 0; ci < 2; ++ci) wf[set][ci] = *(const u32x4 *)(smem + ((wa[ci] ^ kxor) + tap * 8192));
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) MmaW<DT>::run(wf[set][ci], pf[set][pt], acc[ci][pt]);
-        };
+        for (int pt = 0; pt < 2; ++pt) {
+            // (the XOR is recomputed at every use on purpose: hipcc otherwise keeps all 48 (row, shift, slice) addresses of a tile live --
+            // they recur across taps -- and spills into the MFMA loop, with an `s_waitcnt vmcnt(0)` in front of every reload)
+            unsigned a = pa[pt + ky][kx] ^ kxor;
+            asm volatile("" : "+v"(a));
+            pf[set][pt] = *(const u32x4 *)(smem + a);
+        }
+    };
+    bool prefetched = false;                            // the first two steps' fragments of the coming tile are already on their way
+    // one tile; HAVE_OLD: the previous tile's packed rows are pending, their store ops run after MFMA groups 1, 3, 5, ...
+    // next_slot >= 0: the NEXT period is a tile too, its first row of mine in that ring slot -- its addresses and first fragments are
+    // fetched right behind this tile's barrier, under the last step's MFMAs and the conversion
+    auto tile = [&](auto oldc, const Unit &un, int k, int us0, int next_slot) {
+        constexpr bool HAVE_OLD = decltype(oldc)::value;
+        WS_STAMP(3);                                    // between tiles (periods without a tile, unit bookkeeping)
         constexpr bool compute = !(TDRN_WS_ABLATE & 2);
-        if (compute) { LD(0, 0); LD(1, 1); }
-#pragma unroll
-        for (int s = 0; s < 36; ++s) {
+        if (!prefetched) {
+            tile_addresses((us0 + 8 * k + 2 * cw) % kRingRows);
+            if (compute) { LD(0, 0); LD(1, 1); }
+        }
+        auto step = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
             if (compute && s + 2 < 36) LD(s + 2, (s + 2) % 3);
             __builtin_amdgcn_sched_barrier(0);
             if (s == 35) {
@@ -423,105 +563,94 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
                 WS_STAMP(0);                            // steps 0..34
                 __builtin_amdgcn_s_barrier();
                 WS_STAMP(1);                            // barrier (waiting for the producers)
-            }
-            if (compute) MMA(s % 3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- epilogue: ReLU, convert, whole-line stores through my staging strip -------------------------------------------
-        const int n0 = un.nt * 64;
-        const int ty = un.y0 + 8 * k + 2 * cw;          // image row of my first pixel fragment
-        auto stage_quad = [&](const f32x16 &t, int ci, int g, int srow) {
-            float q4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) q4[j] = p.relu ? fmaxf(t[4 * g + j], 0.f) : t[4 * g + j];
-            *(uint2 *)(stg + srow * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * 2) = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
-        };
-        if (p.out && !(TDRN_WS_ABLATE & 4)) {
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll 1
-                for (int rd = 0; rd < 32 / SROWS; ++rd) {
-                    if (r32 / SROWS == rd) {
-#pragma unroll
-                        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, r32 % SROWS);
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xC07F);
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int k2 = 0; k2 < (SROWS * 8 + 63) / 64; ++k2) {
-                        const int idx = lane + 64 * k2, row = idx >> 3, ch = idx & 7;
-                        if (row < SROWS && n0 + ch * 8 < p.Cout) {
-                            const size_t gp = ((size_t)un.b * p.H + ty + pt) * p.W + un.x0 + rd * SROWS + row;
-                            *(u32x4 *)(p.out + (gp * p.Cs + n0 + ch * 8) * 2) = *(const u32x4 *)(stg + row * SSTRIDE + ch * 16);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                if (next_slot >= 0) {                   // (wave-uniform)
+                    tile_addresses(next_slot);
+                    if (compute) { LD(0, 0); LD(1, 1); }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        if (p.out_pool && !(TDRN_WS_ABLATE & 4)) {
-            // fused MaxPool2d(2,2) on the RAW accumulators (max commutes with the monotonic bias + ReLU applied at staging): the
-            // partner row is my other pixel fragment, the partner column lane ^ 1; even-x lanes hold the 16 pooled pixels
-            const int PW = p.W >> 1;
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = fmaxf(acc[ci][0][e], acc[ci][1][e]);
-                    v = fmaxf(v, __shfl_xor(v, 1, 64));
-                    acc[ci][0][e] = v;
-                }
-            const bool holder = (r32 & 1) == 0;
-            const int prow_l = r32 >> 1;
-#pragma unroll 1
-            for (int rd = 0; rd < 16 / SROWS; ++rd) {
-                if (holder && prow_l / SROWS == rd) {
+            if (compute) {
+                if constexpr (s == 0) {                 // the accumulators start at the bias: it is the first MFMAs' C operand
 #pragma unroll
                     for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) stage_quad(acc[ci][0], ci, g, prow_l % SROWS);
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_wave_barrier();
+                        for (int pt = 0; pt < 2; ++pt) {
+                            acc[ci][pt] = cbias[ci];
+                            MmaW<DT>::run(wf[0][ci], pf[0][pt], acc[ci][pt]);
+                        }
+                } else {
 #pragma unroll
-                for (int k2 = 0; k2 < (SROWS * 8 + 63) / 64; ++k2) {
-                    const int idx = lane + 64 * k2, row = idx >> 3, ch = idx & 7;
-                    if (row < SROWS && n0 + ch * 8 < p.Cout) {
-                        const int pl = rd * SROWS + row;                  // pooled pixel of my row pair
-                        const size_t gpool = (size_t)(((size_t)un.b * p.H + ty) >> 1) * PW + ((un.x0 >> 1) + pl);
-                        *(u32x4 *)(p.out_pool + (gpool * p.Cs + n0 + ch * 8) * 2) = *(const u32x4 *)(stg + row * SSTRIDE + ch * 16);
-                    }
+                    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) MmaW<DT>::run(wf[s % 3][ci], pf[s % 3][pt], acc[ci][pt]);
                 }
-                __builtin_amdgcn_wave_barrier();
+            } else if constexpr (s == 0) {
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) acc[ci][pt] = cbias[ci];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // the previous tile's store op (s - 1) / 2 in the shadow of this step's MFMAs
+            if constexpr (HAVE_OLD && (s & 1) && (s >> 1) < NOPS) {
+                store_op(std::integral_constant<int, op_of(s >> 1)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#define WS_S4(b) step(std::integral_constant<int, b>{}); step(std::integral_constant<int, b + 1>{}); step(std::integral_constant<int, b + 2>{}); step(std::integral_constant<int, b + 3>{});
+        WS_S4(0) WS_S4(4) WS_S4(8) WS_S4(12) WS_S4(16) WS_S4(20) WS_S4(24) WS_S4(28) WS_S4(32)
+#undef WS_S4
+        prefetched = next_slot >= 0;
+        // this tile is now the pending one: its packed rows, and where they go
+        convert();
+        const int n0 = un.nt * 64;
+        const int ty = un.y0 + 8 * k + 2 * cw;          // image row of my first pixel fragment
+        if constexpr (MODE & 1) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+                pd_out[pt] = p.out + ((((size_t)un.b * p.H + ty + pt) * p.W + un.x0 + r32) * p.Cs + n0) * 2;
         }
-        WS_STAMP(2);                                    // step 35 + epilogue
+        if constexpr (MODE & 2)
+            pd_pool = p.out_pool + (((size_t)(((size_t)un.b * p.H + ty) >> 1) * (p.W >> 1) + ((un.x0 + r32) >> 1)) * p.Cs + n0) * 2;
+        WS_STAMP(2);                                    // step 35 + conversion
+    };
+    int ntile = 0;
+    auto run_tile = [&](const Unit &tu, int tk, int ts0) {
+        // the next period is a tile as well iff this one is not its unit's last (the period behind a unit's last tile produces the next
+        // unit's rows 8 and 9; the last unit's last tile has no successor)
+        const int next_slot = tk + 1 < tu.T ? (ts0 + 8 * (tk + 1) + 2 * cw) % kRingRows : -1;
+        if (ntile == 0) tile(std::false_type{}, tu, tk, ts0, next_slot);
+        else tile(std::true_type{}, tu, tk, ts0, next_slot);
+        ++ntile;
     };
 
     Unit un = decode(u0), pv = un;
     int us0 = 0, pv_s0 = 0, prev_nt = un.nt;
+    // the consumers are the critical path (the producers wait a third of every period at the barrier): their instructions go first
+    if (TDRN_WS_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     load_weights(un.nt);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // (a)
     write_first_bias();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // (b)
+    load_cbias();
     // periods: unit u, batch j = 0 .. T (u == u1: the one period of the last unit's last tile)
     for (int u = u0; u <= u1; ++u) {
         const int nper = u < u1 ? un.T + 1 : 1;
         for (int j = 0; j < nper; ++j) {
             const bool prev_tile = j == 0 && u > u0, own_tile = j >= 2;
             if (prev_tile || own_tile) {
-                tile(prev_tile ? pv : un, prev_tile ? pv.T - 1 : j - 2, prev_tile ? pv_s0 : us0);
+                run_tile(prev_tile ? pv : un, prev_tile ? pv.T - 1 : j - 2, prev_tile ? pv_s0 : us0);
             } else {
-                if (j == 1 && un.nt != prev_nt) {
+                const bool reload = j == 1 && un.nt != prev_nt;
+                if (reload) {
                     load_weights(un.nt);
                     prev_nt = un.nt;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
+                if (reload) load_cbias();               // (the bias piece landed before wave 0 reached the barrier)
             }
         }
         if (u == u1) break;
@@ -530,6 +659,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
         us0 = (us0 + 8 * un.T + 2) % kRingRows;
         if (u + 1 < u1) un = decode(u + 1);
     }
+    flush();                                            // the last tile's rows
     WS_STAMP_FLUSH;
 }
 
@@ -548,7 +678,7 @@ int conv_ws_enabled()
 int ws_conv_supported(const ConvArgs &a)
 {
     if (!conv_ws_enabled() || (a.kdisable & 64)) return 0;
-    if (a.dtype == TDRN_F32 || a.Cin != 64 || a.Npad % 64) return 0;
+    if (a.dtype == TDRN_F32 || a.Cin != 64 || a.Npad % 64 || a.Cout % 64) return 0;       // (Cout = the output tensor's padded channel count)
     if (a.W % 32 || a.H % 8) return 0;
     return patch_conv_supported(a) != 0;
 }
@@ -556,14 +686,14 @@ int ws_conv_supported(const ConvArgs &a)
 int launch_conv3x3_ws(const ConvArgs &a, void *out_pool, hipStream_t s)
 {
     if (!ws_conv_supported(a)) return TDRN_E_UNSUPPORTED;
-    if (out_pool && ((a.H & 1) || (a.W & 1))) return TDRN_E_UNSUPPORTED;
+    if (out_pool && ((a.H & 1) || (a.W & 1) || !a.relu)) return TDRN_E_UNSUPPORTED;      // (the pooled epilogue's integer maxima assume the ReLU)
     if (!a.out && !out_pool) return TDRN_E_ARG;
     WsParams p;
     p.in = (const char *)a.in; p.w = (const char *)a.w; p.zero = (const char *)a.zero_page; p.bias = a.bias;
     p.out = (char *)a.out; p.out_pool = (char *)out_pool;
     p.B = a.B; p.H = a.H; p.W = a.W; p.Cout = a.Cout; p.Cs = (int)a.o_cs; p.Ktot = 9 * a.Cin;
     p.relu = a.relu;
-    p.SX = a.W / 32; p.TY = a.H / 8; p.NT = a.Npad / 64;
+    p.SX = a.W / 32; p.TY = a.H / 8; p.NT = a.Cout / 64;      // (cout tiles of all-padding rows beyond Cout are not computed)
     p.fx = a.fuse_x; p.fw = a.fuse_w; p.fb = a.fuse_b; p.fS = a.H; p.fCout = a.fuse_cout;
     if (a.fuse_x) {
         // the fused variant keeps LDS for the raw tiles instead of a full staging strip: pooled output only, one cout tile
@@ -624,11 +754,22 @@ int launch_conv3x3_ws(const ConvArgs &a, void *out_pool, hipStream_t s)
         }
     } report{p, s, grid};
 #endif
-#define WS_LAUNCH(DT)                                                                                       \
-    do {                                                                                                    \
-        if (a.fuse_x) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, true>), dim3(grid), dim3(512), 0, s, p);   \
-        else hipLaunchKernelGGL((conv3x3_ws_kernel<DT, false>), dim3(grid), dim3(512), 0, s, p);           \
+#define WS_LAUNCH(DT)                                                                                              \
+    do {                                                                                                           \
+        if (a.fuse_x) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, true, 2>), dim3(grid), dim3(512), 0, s, p);       \
+        else if (mode == 1) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, false, 1>), dim3(grid), dim3(512), 0, s, p); \
+        else hipLaunchKernelGGL((conv3x3_ws_kernel<DT, false, 2>), dim3(grid), dim3(512), 0, s, p);               \
     } while (0)
+    const int mode = (a.out ? 1 : 0) | (out_pool ? 2 : 0);
+    if (mode == 3) return TDRN_E_UNSUPPORTED;            // (both outputs at once: no plan asks for it; conv3x3_patch.hip takes such a launch)
+    // Full-resolution outputs (conv2_1) are eight 1-KiB stores per tile and consumer wave, ~150 cycles of the wave's time each, against two
+    // for a pooled tile: measured in the net 127-128 us against 123-126 us on conv3x3_patch.hip (whose two consumer waves per SIMD hide each
+    // other's stores) -- so this kernel takes such a layer only when asked to (TDRN_CONV_WS=2, the dev harness).  Same bits either way.
+    {
+        static int e = -1;
+        if (e < 0) { const char *v = getenv("TDRN_CONV_WS"); e = v ? atoi(v) : 1; }
+        if (mode == 1 && g_ws_override != 2 && e < 2) return TDRN_E_UNSUPPORTED;
+    }
     if (a.dtype == TDRN_BF16) WS_LAUNCH(bf16_t);
     else WS_LAUNCH(f16_t);
 #undef WS_LAUNCH
