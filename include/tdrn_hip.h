@@ -182,6 +182,11 @@ TDRN_API int tdrn_detect_dev_scale(const float *loc, const float *conf, const fl
  *   bilinear (tests/test_oracle_pin.py); the device kernel is bit-exact against that oracle. */
 TDRN_API int tdrn_preprocess(const uint8_t *frames, int B, int H0, int W0, int S, const float mean_bgr[3],
                              int to_rgb, float *out, void *stream);
+/* The same resize, result left as cv2.resize returns it -- uint8 -- in planes: out (B, 3, S, S) uint8 device, channel-swapped when
+ * to_rgb.  Together with tdrn_net_io.reserved[3] (below) this is SURVEY 8f rank 1 in full: the frame stays uint8 until the first conv's
+ * loader reads it and subtracts the mean there ("fused into the first conv's loader"); no fp32 copy of the batch is ever written.
+ * float(uint8) - mean is exact, so both routes give the net bit-identical inputs (tests/test_gpu_net.py). */
+TDRN_API int tdrn_preprocess_u8(const uint8_t *frames, int B, int H0, int W0, int S, int to_rgb, uint8_t *out, void *stream);
 
 /* ========================================================================================
  * (iii) Whole-network forward -- replaces build_net(...)/RefineSSD.forward:
@@ -293,9 +298,17 @@ typedef struct {
      * frame only through those offsets.  TDRN_E_ARG unless 1 <= Bk <= B and B % Bk == 0.
      * reserved[2] != NULL, with ref_loc: a hipEvent_t that the stream producing the ref_loc maps (the static net's forward, running
      * on ANOTHER stream beside this one) records when they are complete.  The forward waits for it right before its first read of
-     * ref_loc -- behind its trunk, which does not depend on the maps -- instead of the caller serialising the two forwards. */
+     * ref_loc -- behind its trunk, which does not depend on the maps -- instead of the caller serialising the two forwards.
+     * reserved[3] != NULL: a `const tdrn_u8_frames *` -- the batch as UINT8 planes instead of `x` (which may then be NULL): the input
+     * of the net is float(planes[b][c][y][x]) - mean[c].  16-bit plans of the VGG trunks read the planes inside the first conv, which
+     * is computed by conv1_2's producers (conv3x3_ws.hip); every other plan converts them with one small launch into a workspace
+     * tensor first.  Same output bits as the fp32 route. */
     void *reserved[4];
 } tdrn_net_io;
+typedef struct {
+    const uint8_t *planes; /* (B, 3, S, S) uint8, device, in the net's channel order (tdrn_preprocess_u8 with to_rgb as the driver swaps) */
+    float mean[3];         /* per plane, i.e. in the SAME channel order (BGR means (104,117,123) become (123,117,104) behind to_rgb)      */
+} tdrn_u8_frames;
 
 TDRN_API int tdrn_net_forward(tdrn_net *net, const void *weights_dev, void *workspace,
                               size_t workspace_bytes, const tdrn_net_io *io, void *stream);

@@ -45,6 +45,11 @@ class KernelStat(C.Structure):
                 ("bytes", C.c_double), ("ms", C.c_double)]
 
 
+class U8FramesABI(C.Structure):
+    """tdrn_u8_frames (tdrn_hip.h): the batch as uint8 planes + the per-plane mean (tdrn_net_io.reserved[3])"""
+    _fields_ = [("planes", C.c_void_p), ("mean", C.c_float * 3)]
+
+
 class OpInfo(C.Structure):
     _fields_ = [("kind", C.c_int), ("in_", C.c_int), ("out", C.c_int), ("res", C.c_int), ("pool", C.c_int), ("off", C.c_int),
                 ("y", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int), ("relu", C.c_int),
@@ -80,6 +85,7 @@ _SIGS = {
     "tdrn_ota_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "tdrn_preprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "tdrn_preprocess_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "tdrn_detect_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "tdrn_detect": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_double, C.c_void_p,
                                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

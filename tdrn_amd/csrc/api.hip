@@ -235,6 +235,12 @@ int tdrn_preprocess(const uint8_t *frames, int B, int H0, int W0, int S, const f
     return launch_preprocess(frames, B, H0, W0, S, mean_bgr, to_rgb, out, (hipStream_t)stream);
 }
 
+int tdrn_preprocess_u8(const uint8_t *frames, int B, int H0, int W0, int S, int to_rgb, uint8_t *out, void *stream)
+{
+    if (!frames || !out || B <= 0 || H0 <= 0 || W0 <= 0 || S <= 0) return TDRN_E_ARG;
+    return launch_preprocess_u8(frames, B, H0, W0, S, to_rgb, out, (hipStream_t)stream);
+}
+
 size_t tdrn_detect_workspace_bytes(int B, int P, int C, int top_k)
 {
     if (B <= 0 || P <= 0 || C <= 0 || top_k <= 0) return 0;

@@ -559,8 +559,111 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         need_mask = __builtin_amdgcn_readfirstlane(need_mask);
     };
 
-    // ---- epilogue of one item (wave-private staging strip -> whole-line stores) -------------------
+    // ---- epilogue of one item, 16-bit types: straight from the registers (round 5) ---------------------------------------------------
+    // A lane holds, per pixel fragment, WC x 4 groups (ci, g) of 4 couts: group c = 4 ci + g is the 16-byte chunk c of the pixel's span of
+    // BNH couts, of which lane r32 (hh = 0) has the first 8 bytes and lane r32 + 32 the second.  v_permlane32_swap on a PAIR of chunks
+    // (c, c + 1) gives the lower lane all 16 bytes of chunk c and the upper lane all of chunk c + 1 (cdna_hip_programming.md T21): one
+    // dwordx4 store per pair, 32 contiguous bytes per pixel and instruction -- no staging strip, no LDS round trips, no wave barriers.
+    // Same values as the staged version (bias is in the accumulators; ReLU is a signed 16-bit maximum with 0 on the PACKED pair, exact for
+    // finite values; the conversion is the same v_cvt_pk).  Pooled output: the window's four (TW = 16) or two (TW = 32: the partner row is
+    // my other pixel fragment) lanes hold the same maxima after the lane exchanges (DPP quad permute for lane ^ 1, v_permlane16_swap for
+    // lane ^ 16) and each stores a different chunk pair of the same pooled pixel.
+    typedef short pk_s2 __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] const pk_s2 relu_lo = p.relu ? pk_s2{0, 0} : pk_s2{(short)-32768, (short)-32768};
+    auto pack_relu16 = [&](float a, float b) -> unsigned {
+        if constexpr (sizeof(DT) == 2) return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, pack2<DT>(a, b)), relu_lo));
+        else return 0u;
+    };
+    auto epilogue16 = [&]() {
+        if constexpr (sizeof(DT) == 2) {
+            const int cbase = n0 + chalf * BNH;                 // first cout of my span
+            constexpr int NPAIR = 2 * WC;                       // chunk pairs per pixel (2 or 4)
+            if (p.out && !(TDRN_PATCH_ABLATE & 4)) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int i = cw * 64 + pt * 32 + r32;
+                    long long gp;
+                    if (TW) gp = tile_pix0 + (long long)(i >> LGTW) * p.W + (i & (TW - 1));
+                    else { gp = tile_pix0 + i; if (gp >= p.M) gp = -1; }
+                    char *row = p.out + ((size_t)(gp < 0 ? 0 : gp) * p.Cs + cbase) * 2;
+#pragma unroll
+                    for (int pr = 0; pr < NPAIR; ++pr) {
+                        const int ci = pr >> 1, g0 = 2 * (pr & 1);
+                        const f32x16 &t = acc[ci][pt];
+                        const unsigned ax = pack_relu16(t[4 * g0], t[4 * g0 + 1]), ay = pack_relu16(t[4 * g0 + 2], t[4 * g0 + 3]);
+                        const unsigned bx = pack_relu16(t[4 * g0 + 4], t[4 * g0 + 5]), by = pack_relu16(t[4 * g0 + 6], t[4 * g0 + 7]);
+                        auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                        if (gp >= 0 && cbase + (2 * pr + hh) * 8 < p.Cout)
+                            *(u32x4 *)(row + (2 * pr + hh) * 16) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                    }
+                }
+            }
+            if constexpr (TW != 0) if (p.out_pool) {
+                // fused MaxPool2d(2,2) on the RAW accumulators (max commutes with the monotonic bias + ReLU + rounding applied afterwards)
+                const int PW = p.W >> 1;
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    if (TW == 32 && pt == 1) break;
+                    uint2 pk[WC][4];
+#pragma unroll
+                    for (int ci = 0; ci < WC; ++ci)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float m[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float v = acc[ci][pt][4 * g + j];
+                                if (TW == 32) {
+                                    v = fmaxf(v, acc[ci][1][4 * g + j]);
+                                } else {
+                                    // lane ^ 16: rows of 16 lanes; v_permlane16_swap exchanges the odd rows of its first operand with the even
+                                    // rows of its second: from two copies of v it leaves (lower row | it again) and (upper row | it again), whose
+                                    // maximum is the row pair's.  Inline asm on two registers of their own (through the builtin, given the same value
+                                    // twice, hipcc dropped the second result: the pooled maxima of conv3_3 came out wrong in 29 % of the outputs);
+                                    // the two wait states a VALU write needs before the swap reads it are inside the string.
+                                    float va = v, vb = v;
+                                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(va), "+v"(vb));
+                                    v = fmaxf(va, vb);
+                                }
+                                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+                                m[j] = v;
+                            }
+                            pk[ci][g] = make_uint2(pack_relu16(m[0], m[1]), pack_relu16(m[2], m[3]));
+                        }
+                    // my pixel's window -> pooled pixel; the window's lanes (2 for TW = 32, 4 for TW = 16) take different chunk pairs
+                    const int i = cw * 64 + pt * 32 + r32;
+                    const long long gpool = (long long)((tile_row0 + (i >> LGTW)) >> 1) * PW + ((tile_x0 + (i & (TW - 1))) >> 1);
+                    char *row = p.out_pool + ((size_t)gpool * p.Cs + cbase) * 2;
+                    constexpr int NDUP = TW == 32 ? 2 : 4;      // lanes holding the same window
+                    const int sel = TW == 32 ? (r32 & 1) : ((r32 & 1) | ((r32 >> 3) & 2));
+#pragma unroll
+                    for (int rd = 0; rd < (NPAIR + NDUP - 1) / NDUP; ++rd) {
+                        // my chunk pair of this round: rd * NDUP + sel (a runtime index into registers: selected with compares)
+                        uint2 a = pk[0][0], b = pk[0][1];
+#pragma unroll
+                        for (int d = 0; d < NDUP; ++d) {
+                            const int pr = rd * NDUP + d;
+                            if (pr < NPAIR) {
+                                const bool mine = sel == d;
+                                a.x = mine ? pk[pr >> 1][2 * (pr & 1)].x : a.x; a.y = mine ? pk[pr >> 1][2 * (pr & 1)].y : a.y;
+                                b.x = mine ? pk[pr >> 1][2 * (pr & 1) + 1].x : b.x; b.y = mine ? pk[pr >> 1][2 * (pr & 1) + 1].y : b.y;
+                            }
+                        }
+                        const int mypr = rd * NDUP + sel;
+                        auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+                        if (mypr < NPAIR && cbase + (2 * mypr + hh) * 8 < p.Cout)
+                            *(u32x4 *)(row + (2 * mypr + hh) * 16) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- epilogue of one item, fp32 (wave-private staging strip -> whole-line stores) -------------------
     auto epilogue = [&]() {
+        if constexpr (sizeof(DT) == 2) { epilogue16(); return; }
         const int my_c = n0 + chalf * BNH + my_ch * P16;
         auto pixel_of = [&](int i) -> long long {       // global pixel of tile-local pixel i (or -1)
             if (TW) return tile_pix0 + (long long)(i >> LGTW) * p.W + (i & (TW - 1));

@@ -362,26 +362,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
             *(uint2 *)d = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
         };
         if (p.out && !(TDRN_PP_ABLATE & 4)) {
+            // Round 5: straight from the registers.  Group c = 4 ci + g is the 16-byte chunk c of my pixel's span of 128 couts; lane r32 has its
+            // first 8 bytes, lane r32 + 32 the second: v_permlane32_swap on a chunk PAIR gives each of the two lanes one whole chunk
+            // (cdna_hip_programming.md T21) -> eight dwordx4 stores per pixel fragment, no staging strip, no LDS round trips, no wave barriers.
+            // ReLU as a signed 16-bit maximum with 0 on the packed pair (exact for finite values); same v_cvt_pk as before: same bits.
+            typedef short pk_s2 __attribute__((ext_vector_type(2)));
+            const pk_s2 relu_lo = p.relu ? pk_s2{0, 0} : pk_s2{(short)-32768, (short)-32768};
+            auto pk = [&](float a, float b) -> unsigned {
+                return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, pack2<DT>(a, b)), relu_lo));
+            };
+            const int cbase = n0 + grp * BNH;
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll 1
-                for (int rd = 0; rd < 32 / SROWS; ++rd) {
-                    if (r32 / SROWS == rd) {            // lanes whose pixel is in this round
+                const long long gp = pixel_of(cw * 64 + pt * 32 + r32);
+                char *row = p.out + ((size_t)(gp < 0 ? 0 : gp) * p.Cs + cbase) * ES;
 #pragma unroll
-                        for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, r32 % SROWS);
-                    }
-                    PP_LGKM0();                         // my LDS writes are done
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int k = 0; k < SROWS / RPI; ++k) {
-                        const int row = my_row + k * RPI;
-                        const long long gp = pixel_of(cw * 64 + pt * 32 + rd * SROWS + row);
-                        if (gp >= 0 && my_c < p.Cout)
-                            *(u32x4 *)(p.out + ((size_t)gp * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
-                    }
-                    __builtin_amdgcn_wave_barrier();     // (a wave's DS instructions execute in order)
+                for (int pr = 0; pr < 2 * WC; ++pr) {
+                    const int ci = pr >> 1, g0 = 2 * (pr & 1);
+                    const f32x16 &t = acc[ci][pt];
+                    const unsigned ax = pk(t[4 * g0], t[4 * g0 + 1]), ay = pk(t[4 * g0 + 2], t[4 * g0 + 3]);
+                    const unsigned bx = pk(t[4 * g0 + 4], t[4 * g0 + 5]), by = pk(t[4 * g0 + 6], t[4 * g0 + 7]);
+                    auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    if (gp >= 0 && cbase + (2 * pr + hh) * 8 < p.Cout)
+                        *(u32x4 *)(row + (2 * pr + hh) * 16) = u32x4{rx[0], ry[0], rx[1], ry[1]};
                 }
             }
         }

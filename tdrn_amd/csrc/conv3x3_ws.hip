@@ -45,6 +45,10 @@ struct WsParams {
     // FUSE: the layer's input is the first conv's output, computed here from the raw frames
     const float *fx, *fw, *fb;     // frames NCHW fp32 [B][3][S][S]; first-conv weights [64][27] (k = c*9 + r*3 + q) and bias [64], fp32
     int fS, fCout;
+    // U8: the frames as uint8 planes [B][3][S][S] instead of fx; the net input is float(byte) - fmean[plane] (the
+    // frame is read, and its mean subtracted, inside the first conv's loader)
+    const unsigned char *fx8;
+    float fmean[3];
 #ifdef TDRN_WS_STAMP
     unsigned *stamps;              // diagnostics build only: [workgroup][wave][4] cycle sums (s_memtime), see the launcher
 #endif
@@ -114,8 +118,9 @@ constexpr int kRawBytes = kRawPieces * 256;             // 4352 per buffer
 
 }  // namespace
 
-// MODE: 1 = full-resolution output, 2 = fused MaxPool2d(2,2) output, 3 = both (compile-time: the epilogue's ops sit inside the MFMA loop)
-template <typename DT, bool FUSE, int MODE>
+// MODE: 1 = full-resolution output, 2 = fused MaxPool2d(2,2) output (compile-time: the epilogue's ops sit inside the MFMA loop)
+// U8 (FUSE only): the raw frames are uint8 planes
+template <typename DT, bool FUSE, int MODE, bool U8 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
 {
     static_assert(sizeof(DT) == 2, "16-bit element types only");
@@ -179,6 +184,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
         const int lw = wave - 4;
         // ---- FUSE: lane constants of the raw-tile loads and of the first conv ---------------------------------------------
         [[maybe_unused]] int r_rc[FUSE ? 5 : 1], r_off[FUSE ? 5 : 1];
+        [[maybe_unused]] float r_mean[U8 ? 5 : 1];               // U8: the mean of my element's plane
+        [[maybe_unused]] unsigned r_byte[U8 ? 5 : 1];            // U8: the bytes of the NEXT batch's raw tile, loaded a period ahead (0x100: outside the frame)
         [[maybe_unused]] int koff1[16];
         [[maybe_unused]] u32x4 wq1[2][2];
         if constexpr (FUSE) {
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
                 const int r = rem / kRawCols, q = rem - r * kRawCols;
                 r_rc[j] = i < kRawN ? ((r << 8) | q) : -1;
                 r_off[j] = (c * p.fS + r) * p.fS + q;
+                if constexpr (U8) { r_mean[j] = c == 0 ? p.fmean[0] : (c == 1 ? p.fmean[1] : p.fmean[2]); r_byte[j] = 0x100u; }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
@@ -211,8 +219,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
         // a batch: `nrows` patch rows starting at image row yf (may lie outside the image) of strip x0 of image b -> ring slots s0 ..
         struct Batch { int b, x0, yf, nrows, s0; };
         // raw halo tile of a batch -> raw buffer `buf` (my pieces)
+        // U8: the raw tile's bytes are fetched into registers when issue_raw is called (ordinary byte loads, one period ahead of their use)
+        // and turned into the fp32 tile by land_raw at the END of the period -- float(byte) - mean, 0 outside the frame: the same values the
+        // fp32 route finds in its tile
+        auto land_raw = [&](int buf) {
+            if constexpr (U8) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if ((lw + 4 * j) >= kRawPieces) continue;
+                    *(float *)(smem + OFF_RAW + buf * kRawBytes + (lw + 4 * j) * 256 + lane * 4) = r_byte[j] < 0x100u ? (float)r_byte[j] - r_mean[j] : 0.f;
+                }
+            }
+        };
         auto issue_raw = [&](const Batch &bt, int buf) {
-            if constexpr (FUSE) {
+            if constexpr (U8) {
+                const unsigned char *xb = p.fx8 + (size_t)bt.b * 3 * p.fS * p.fS + ((long long)(bt.yf - 1) * p.fS + (bt.x0 - 2));
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if ((lw + 4 * j) >= kRawPieces) continue;
+                    const int rr = r_rc[j] >> 8, cc = r_rc[j] & 0xff;
+                    const int yy = bt.yf - 1 + rr, xx = bt.x0 - 2 + cc;
+                    const bool ok = r_rc[j] >= 0 && rr < bt.nrows + 2 && (unsigned)yy < (unsigned)p.fS && (unsigned)xx < (unsigned)p.fS;
+                    r_byte[j] = ok ? (unsigned)xb[r_off[j]] : 0x100u;
+                }
+                (void)buf;
+            } else if constexpr (FUSE) {
                 const char *xb = (const char *)(p.fx + (size_t)bt.b * 3 * p.fS * p.fS + ((long long)(bt.yf - 1) * p.fS + (bt.x0 - 2)));
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
@@ -345,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
         int us0 = 0;                                    // ring slot of the unit's first row (runs on across units)
         load_weights(un.nt);
         if constexpr (FUSE) issue_raw(batch_of(un, 0, us0), 0);
+        land_raw(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // (a) weights, bias and the first raw tile landed
         write_first_bias();
@@ -382,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const WsParams p)
                         dma_rows(bt);
                     }
                 }
+                land_raw((n + 1) & 1);                  // (U8: the next batch's tile; nobody has read that buffer since the barrier before last)
                 WS_STAMP(0);                            // production (issue / first conv)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 WS_STAMP(1);                            // landing of the DMA pieces
@@ -695,7 +728,9 @@ int launch_conv3x3_ws(const ConvArgs &a, void *out_pool, hipStream_t s)
     p.relu = a.relu;
     p.SX = a.W / 32; p.TY = a.H / 8; p.NT = a.Cout / 64;      // (cout tiles of all-padding rows beyond Cout are not computed)
     p.fx = a.fuse_x; p.fw = a.fuse_w; p.fb = a.fuse_b; p.fS = a.H; p.fCout = a.fuse_cout;
-    if (a.fuse_x) {
+    p.fx8 = a.fuse_x8; p.fmean[0] = a.fuse_mean[0]; p.fmean[1] = a.fuse_mean[1]; p.fmean[2] = a.fuse_mean[2];
+    if (a.fuse_x && a.fuse_x8) return TDRN_E_ARG;
+    if (a.fuse_x || a.fuse_x8) {
         // the fused variant keeps LDS for the raw tiles instead of a full staging strip: pooled output only, one cout tile
         if (a.out || !out_pool || p.NT != 1 || a.H != a.W || a.fuse_cout > 64) return TDRN_E_UNSUPPORTED;
     }
@@ -750,13 +785,14 @@ int launch_conv3x3_ws(const ConvArgs &a, void *out_pool, hipStream_t s)
             const double tiles = (double)p.units * p.TSEG / grid;
             fprintf(stderr, "ws_stamp H%d W%d Cout%d fuse%d TSEG%d units%d tiles/CU~%.1f | consumer cyc/wave: steps0-34 %.0f barrier %.0f step35+epilogue %.0f between %.0f"
                             " | producer cyc/wave: produce %.0f landing %.0f barrier %.0f\n",
-                    p.H, p.W, p.Cout, p.fx ? 1 : 0, p.TSEG, p.units, tiles, c[0] / nc, c[1] / nc, c[2] / nc, c[3] / nc, l[0] / nl, l[1] / nl, l[2] / nl);
+                    p.H, p.W, p.Cout, (p.fx || p.fx8) ? 1 : 0, p.TSEG, p.units, tiles, c[0] / nc, c[1] / nc, c[2] / nc, c[3] / nc, l[0] / nl, l[1] / nl, l[2] / nl);
         }
     } report{p, s, grid};
 #endif
 #define WS_LAUNCH(DT)                                                                                              \
     do {                                                                                                           \
-        if (a.fuse_x) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, true, 2>), dim3(grid), dim3(512), 0, s, p);       \
+        if (a.fuse_x8) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, true, 2, true>), dim3(grid), dim3(512), 0, s, p); \
+        else if (a.fuse_x) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, true, 2>), dim3(grid), dim3(512), 0, s, p);  \
         else if (mode == 1) hipLaunchKernelGGL((conv3x3_ws_kernel<DT, false, 1>), dim3(grid), dim3(512), 0, s, p); \
         else hipLaunchKernelGGL((conv3x3_ws_kernel<DT, false, 2>), dim3(grid), dim3(512), 0, s, p);               \
     } while (0)

@@ -39,6 +39,9 @@ struct ConvArgs {
     // patch kernel, first conv fused in (conv3x3_patch.hip FUSE): frames NCHW fp32, the first conv's folded weights [c][27] and bias
     const float *fuse_x = nullptr, *fuse_w = nullptr, *fuse_b = nullptr;
     int fuse_cout = 0;
+    // ... or the frames as uint8 planes (B, 3, S, S) with the per-plane mean still to be subtracted (conv3x3_ws.hip only: tdrn_net_io.reserved[3])
+    const unsigned char *fuse_x8 = nullptr;
+    float fuse_mean[3] = {0.f, 0.f, 0.f};
     int max_wgs = 0;                // patch kernel: > 0 caps the persistent grid (a multiple of 8), leaving CUs to concurrent lanes
     void *sk_ws = nullptr;          // conv3x3_pp.hip: scratch of conv_pp_sk_bytes() for the chained split (one launch at a time), or null
     bool sk_flags_zero = false;     // the first 1024 bytes of sk_ws are zero on entry (every launch leaves them zero): no memset node
@@ -137,6 +140,8 @@ int launch_nhwc_to_nchw_f32(const float *in, long long in_bs, long long in_ps, f
 int launch_nhwc_any_to_nchw_f32(const void *in, int dtype, int Cpad, float *out, int B, int C, int HW, hipStream_t s);
 int launch_preprocess(const unsigned char *in, int B, int H0, int W0, int S, const float *mean_bgr, int to_rgb, float *out,
                       hipStream_t s);
+int launch_preprocess_u8(const unsigned char *in, int B, int H0, int W0, int S, int to_rgb, unsigned char *out, hipStream_t s);   // resized uint8 planes
+int launch_u8_planes_to_f32(const unsigned char *in, int B, int S, const float *mean, float *out, hipStream_t s);                // (B,3,S,S) u8 -> fp32 - mean[c]
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

@@ -948,6 +948,64 @@ int launch_preprocess(const unsigned char *in, int B, int H0, int W0, int S, con
     return hip_status(hipGetLastError());
 }
 
+// The same resize with the result left as what cv2.resize returns: uint8, planar (B, 3, S, S), channel-swapped on request -- a quarter of
+// the fp32 tensor; the mean is subtracted where the frame is read (conv3x3_ws.hip's producers, or u8_planes_to_f32 below).
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char *__restrict__ in, int B, int H0, int W0, int S, int to_rgb,
+                                                            unsigned char *__restrict__ out)
+{
+    const long long total = (long long)B * S * S;
+    const double sx = (double)W0 / S, sy = (double)H0 / S;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int dx = (int)(i % S), dy = (int)((i / S) % S), b = (int)(i / ((long long)S * S));
+        int x0, a0, a1, y0, b0, b1;
+        cv_coef(dx, sx, W0, x0, a0, a1);
+        cv_coef(dy, sy, H0, y0, b0, b1);
+        const int x1 = x0 + 1 < W0 ? x0 + 1 : x0, y1 = y0 + 1 < H0 ? y0 + 1 : y0;
+        const unsigned char *r0 = in + (((size_t)b * H0 + y0) * W0) * 3, *r1 = in + (((size_t)b * H0 + y1) * W0) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+            const int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            const int oc = to_rgb ? 2 - c : c;
+            out[(((size_t)b * 3 + oc) * S + dy) * S + dx] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+int launch_preprocess_u8(const unsigned char *in, int B, int H0, int W0, int S, int to_rgb, unsigned char *out, hipStream_t s)
+{
+    const long long total = (long long)B * S * S;
+    if (total <= 0) return TDRN_OK;
+    dim3 grid((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256));
+    hipLaunchKernelGGL(preprocess_u8_kernel, grid, dim3(256), 0, s, in, B, H0, W0, S, to_rgb, out);
+    return hip_status(hipGetLastError());
+}
+
+// uint8 planes (B, 3, S, S) -> fp32 (B, 3, S, S) minus the per-plane mean: the net input for the plans whose first conv is a launch of
+// its own (fp32 mode, stride-2 trunks); float(u8) - mean is exact, so both routes feed the first conv the same values
+__global__ __launch_bounds__(256) void u8_planes_to_f32_kernel(const unsigned char *__restrict__ in, long long plane, long long total, float m0,
+                                                               float m1, float m2, float *__restrict__ out)
+{
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * 256 * 4) {
+        const int c = (int)((i / plane) % 3);
+        const float m = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        const uchar4 v = *(const uchar4 *)(in + i);            // (plane is a multiple of 4: S is a multiple of 64)
+        *(float4 *)(out + i) = make_float4((float)v.x - m, (float)v.y - m, (float)v.z - m, (float)v.w - m);
+    }
+}
+
+int launch_u8_planes_to_f32(const unsigned char *in, int B, int S, const float *mean, float *out, hipStream_t s)
+{
+    const long long plane = (long long)S * S, total = plane * 3 * B;
+    if (total <= 0) return TDRN_OK;
+    if (plane % 4) return TDRN_E_UNSUPPORTED;
+    const long long th = total / 4;
+    dim3 grid((unsigned)((th + 255) / 256 > 8192 ? 8192 : (th + 255) / 256));
+    hipLaunchKernelGGL(u8_planes_to_f32_kernel, grid, dim3(256), 0, s, in, plane, total, mean[0], mean[1], mean[2], out);
+    return hip_status(hipGetLastError());
+}
+
 int launch_fill_zero(void *p, size_t bytes, hipStream_t s)
 {
     return hip_status(hipMemsetAsync(p, 0, bytes, s));

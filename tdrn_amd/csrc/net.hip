@@ -173,6 +173,7 @@ struct tdrn_net {
     size_t chain_partial_off = 0;        // the chain's split-K slab region (bytes per sample from workspace start)
     bool pp_sk_planned = false;          // some main-lane conv may use conv3x3_pp.hip's chained split
     int fuse_first = -1;                 // index of the conv whose patch loader computes the first conv itself (16-bit modes), or -1
+    int x_t = -1;                        // fp32 (3, S, S) workspace tensor: the net input when the caller hands uint8 planes to a plan whose first conv reads fp32
     int late_side = 1, side_grid = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
@@ -221,6 +222,7 @@ struct tdrn_net {
     int first_conv(const std::string &w, bool bias, const std::string &bn, int Cout, int stride, int S)
     {
         const int So = (S + 2 - 3) / stride + 1;
+        x_t = T(3, S, S, true);
         Op o; o.kind = OP_FIRST; o.stat = ST_FIRST;
         o.Cin = 3; o.Cout = Cout; o.stride = stride; o.relu = 1; o.hw = S;
         o.w = w; o.bn = bn;
@@ -1100,7 +1102,12 @@ struct tdrn_net {
     int forward(const void *blob, void *ws, size_t ws_bytes, const tdrn_net_io *io, hipStream_t s0)
     {
         if (!weights_ready) return TDRN_E_STATE;
-        if (!blob || !ws || !io || !io->x || io->batch <= 0) return TDRN_E_ARG;
+        if (!blob || !ws || !io || io->batch <= 0) return TDRN_E_ARG;
+        // the batch: fp32 (B,3,S,S) in io->x, or uint8 planes + per-plane mean (tdrn_net_io.reserved[3]); `xin` = the fp32 tensor the first
+        // conv reads, null until the uint8 planes have been converted (which only happens when no kernel reads them directly)
+        const tdrn_u8_frames *u8 = (const tdrn_u8_frames *)io->reserved[3];
+        if (u8 ? !u8->planes : !io->x) return TDRN_E_ARG;
+        const float *xin = u8 ? nullptr : io->x;
         const int B = io->batch;
         if (ws_bytes < ws_per_sample * (size_t)B + ws_fixed) return TDRN_E_WORKSPACE;
         if (!io->conf) return TDRN_E_ARG;
@@ -1288,7 +1295,12 @@ struct tdrn_net {
             int rc = TDRN_OK;
             switch (o.kind) {
                 case OP_FIRST:
-                    rc = launch_first_conv(io->x, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off), tptr(ws, o.out, B),
+                    if (!xin) {
+                        rc = launch_u8_planes_to_f32(u8->planes, B, cfg.size, u8->mean, (float *)tptr(ws, x_t, B), s);
+                        if (rc != TDRN_OK) break;
+                        xin = (const float *)tptr(ws, x_t, B);
+                    }
+                    rc = launch_first_conv(xin, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off), tptr(ws, o.out, B),
                                            B, o.hw, o.stride, o.Cout, tensors[o.out].Cpad, o.relu, cfg.dtype, s);
                     break;
                 case OP_CONV: {
@@ -1333,14 +1345,29 @@ struct tdrn_net {
                         }
                     }
                     if ((int)oi == fuse_first) {
-                        a.fuse_x = io->x; a.fuse_w = (const float *)(wb + ops[0].w_off); a.fuse_b = (const float *)(wb + ops[0].b_off);
+                        a.fuse_w = (const float *)(wb + ops[0].w_off); a.fuse_b = (const float *)(wb + ops[0].b_off);
                         a.fuse_cout = ops[0].Cout;
+                        if (!xin && o.pool_t >= 0) {
+                            // uint8 frames: conv3x3_ws.hip's producers read the planes themselves (the frame never exists in fp32)
+                            a.fuse_x8 = u8->planes; a.fuse_mean[0] = u8->mean[0]; a.fuse_mean[1] = u8->mean[1]; a.fuse_mean[2] = u8->mean[2];
+                            a.out = nullptr;
+                            rc = ws_conv_supported(a) ? launch_conv3x3_ws(a, tptr(ws, o.pool_t, B), s) : TDRN_E_UNSUPPORTED;
+                            if (rc != TDRN_E_UNSUPPORTED) break;          // (done, or a real error)
+                            a.fuse_x8 = nullptr;
+                            a.out = tptr(ws, o.out, B);
+                        }
+                        if (!xin) {                                       // it declined (a small batch): the fp32 route from here on
+                            rc = launch_u8_planes_to_f32(u8->planes, B, cfg.size, u8->mean, (float *)tptr(ws, x_t, B), s);
+                            if (rc != TDRN_OK) break;
+                            xin = (const float *)tptr(ws, x_t, B);
+                        }
+                        a.fuse_x = xin;
                     }
                     if (a.fuse_x && !(conv_patch_enabled() && patch_conv_supported(a) > 0)) {
                         // the fusion was planned from the layer geometry; should the patch kernel decline THIS launch (a limit
                         // that depends on the batch), run the two layers as two launches: the first conv's tensor keeps its place
                         // in the workspace
-                        rc = launch_first_conv(io->x, a.fuse_w, a.fuse_b, tptr(ws, ops[0].out, B), B, ops[0].hw, ops[0].stride, ops[0].Cout,
+                        rc = launch_first_conv(xin, a.fuse_w, a.fuse_b, tptr(ws, ops[0].out, B), B, ops[0].hw, ops[0].stride, ops[0].Cout,
                                                tensors[ops[0].out].Cpad, ops[0].relu, cfg.dtype, s);
                         if (rc != TDRN_OK) break;
                         a.fuse_x = nullptr; a.fuse_w = nullptr; a.fuse_b = nullptr; a.fuse_cout = 0;

@@ -115,12 +115,15 @@ class NetEngine(object):
 
     def forward(self, x, want_offsets=False, ref_loc=None, want_loc_maps=False, out=None, reuse_offsets_token=None, first_op=0,
                 ref_event=None):
+        u8 = None
+        if hasattr(x, "planes"):                        # tdrn_amd.data.U8Frames: the batch stays uint8 (tdrn_net_io.reserved[3])
+            u8, x = x, x.planes
         _lib.require_cuda(x, "input")
         if self.weights is None:
             raise RuntimeError("weights were never packed (load() / broadcast_weights())")
         if x.dim() != 4 or x.size(1) != 3 or x.size(2) != self.cfg.size or x.size(3) != self.cfg.size:
             raise ValueError("expected input (B,3,%d,%d), got %r" % (self.cfg.size, self.cfg.size, tuple(x.shape)))
-        x = x.contiguous().float()
+        x = x.contiguous() if u8 is not None else x.contiguous().float()
         B, P, Cn = x.size(0), self.num_priors, self.num_classes
         dev = x.device
         ws = self.workspace(B)
@@ -139,7 +142,11 @@ class NetEngine(object):
         if conf is None:
             conf = torch.empty((B * P, Cn), dtype=torch.float32, device=dev)
         io = NetIO()
-        io.x = x.data_ptr()
+        if u8 is None:
+            io.x = x.data_ptr()
+        else:
+            frames = _lib.U8FramesABI(planes=x.data_ptr(), mean=(C.c_float * 3)(*u8.mean))
+            io.reserved[3] = C.addressof(frames)        # (read during the call below; `frames` lives until this function returns)
         io.batch = B
         io.arm_loc = arm_loc.data_ptr() if arm_loc is not None else None
         io.odm_loc = odm_loc.data_ptr() if odm_loc is not None else None

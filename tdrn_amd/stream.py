@@ -26,7 +26,7 @@ half-overwritten) result.
 """
 import torch
 
-from .data import base_transform
+from .data import base_transform_u8
 
 AHEAD = 2        # batches copied in ahead of the one being computed
 
@@ -64,7 +64,9 @@ class FrameStream(object):
 
         def make_step(eng, det):
             def one_step(u8):
-                x = base_transform(u8, size, mean)
+                # the frame stays uint8 until the first conv's loader reads it: resize to uint8 planes, a quarter of the
+                # fp32 tensor; the mean is subtracted inside the net (tdrn_net_io.reserved[3])
+                x = base_transform_u8(u8, size, mean)
                 r = eng.forward(x)
                 return det.forward(r["odm_loc"], r["conf"], priors, arm_loc_data=r["arm_loc"], scale=scale)
             return one_step

@@ -1021,3 +1021,34 @@ def test_frame_stream_with_two_pipelines_equals_unstreamed():
         assert torch.equal(got, fs.eager(feeds[k].to(DEV)).cpu()), k
     with pytest.raises(ValueError):
         FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=3, calibrate=False)
+
+
+@pytest.mark.parametrize("model,args,dtype,batches", [
+    ("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True), "bf16", (32, 1, 5)),      # conv3x3_ws.hip's producers read the uint8 planes
+    ("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True), "fp16", (3,)),
+    ("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True), "fp32", (2,)),             # first conv a launch of its own: planes converted first
+    ("dualrefinedet_mobilenet", (320, 21, 1, True), "fp16", (4,)),                     # stride-2 first conv
+    ("ssd4scale_vgg", (320, 21, 1024, False, False), "bf16", (8,)),
+])
+def test_uint8_frames_equal_fp32_frames(model, args, dtype, batches):
+    """SURVEY 8f rank 1 in full: frames stay uint8 until the first conv reads them (tdrn_preprocess_u8 -> tdrn_net_io.reserved[3]).
+    net(U8Frames) == net(base_transform(...)) bit for bit on every output, for the plans that read the planes inside conv1_2's producers
+    and for the ones that convert them first; and the uint8 resize is the fp32 preprocess before its mean subtraction."""
+    from tdrn_amd.data import base_transform, base_transform_u8
+    net, _ = _build(model, args)
+    net.set_compute_dtype(dtype)
+    rng = np.random.RandomState(17)
+    for B in batches:
+        frames = torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)).to(DEV)
+        for to_rgb in (True, False):
+            xf = base_transform(frames, 320, (104, 117, 123), to_rgb)
+            xu = base_transform_u8(frames, 320, (104, 117, 123), to_rgb)
+            assert xu.planes.dtype == torch.uint8 and torch.equal(xu.float(), xf)
+        want = net(xf)
+        got = net(xu)
+        for u, v in zip(want, got):
+            if torch.is_tensor(u):
+                assert torch.equal(u, v), (model, dtype, B)
+            elif u is not None:
+                for uu, vv in zip(u, v):
+                    assert torch.equal(uu, vv), (model, dtype, B)
