@@ -939,7 +939,11 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
         const int rc = launch_conv3x3_ws(a, out_pool, s);
         if (rc != TDRN_E_UNSUPPORTED) return rc;         // (it declines launches too small to fill the chip and fused launches it has no LDS for)
     }
-    if (!out_pool && pp_conv_supported(a)) {             // conv3x3_pp.hip: same arithmetic, same bits
+    // (pooled layers stay here: conv3x3_pp.hip's POOL instantiation no longer spills with the register-only epilogue and is bit-identical --
+    // tests/test_gpu_pin16.py ran green on it -- but conv3_3 measured 210 us there against 204-210 us here: no gain; TDRN_PP_POOL=1 selects it)
+    static int pp_pool = -1;
+    if (pp_pool < 0) { const char *e = getenv("TDRN_PP_POOL"); pp_pool = e ? atoi(e) : 0; }
+    if ((!out_pool || pp_pool) && pp_conv_supported(a)) {    // conv3x3_pp.hip: same arithmetic, same bits
         const int rc = launch_conv3x3_pp(a, out_pool, s);
         if (rc != TDRN_E_UNSUPPORTED) return rc;         // (it declines launches too small to fill the chip)
     }

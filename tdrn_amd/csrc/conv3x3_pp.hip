@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     constexpr bool FLAT = TW == 0;
     constexpr int LGTW = TW == 32 ? 5 : 4;
     constexpr int TH = TW ? 256 / TW : 0;
-    constexpr int ES = 2, P16 = 8;
+    constexpr int ES = 2;
     constexpr int BN = 256, BNH = 128, WC = 4;
     constexpr int PBYTES = kPPSlots * 1024;
     constexpr int WBYTES = BN * 128;                    // one weight slot: 32 KiB (two group halves of 16 KiB)
@@ -301,8 +301,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
     // =========================== compute state ===========================
     f32x16 acc[WC][2];
     unsigned tapmask[2] = {0x1FFu, 0x1FFu};             // flat mode: bit t = tap t inside the image
-    constexpr int CPR = BNH * ES / 16;                  // 16-B chunks per pixel (my cout half): 16
-    constexpr int RPI = 64 / CPR;                       // staging rows copied per wave pass: 4
     constexpr bool compute = !(TDRN_PP_ABLATE & 2);
 
     int cur_mt = -1, n0 = 0;
@@ -340,26 +338,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
         }
     };
 
-    // ---- epilogue of one item (wave-private staging strip in the dead patch buffer -> whole-line stores) ----------
-    auto epilogue = [&](char *stg) {
+    // ---- epilogue of one item: straight from the registers (round 5; rounds 3-4 staged every tile through a strip in the dead patch buffer) ----
+    auto epilogue = [&](char *) {
         // lane-derived constants are re-derived here from an opaque copy of the lane id: hoisted out of the step loop they
         // would be live (or spilled and re-loaded behind a vmcnt(0)) across every multiply segment
         const int ln = opaque_lane();
         const int r32 = ln & 31, hh = ln >> 5;
-        const int my_ch = ln % CPR, my_row = ln / CPR;
-        const int my_c = n0 + grp * BNH + my_ch * P16;
         auto pixel_of = [&](int i) -> long long {       // global pixel of tile-local pixel i (or -1)
             if (TW) return tile_pix0 + (long long)(i >> LGTW) * p.W + (i & (TW - 1));
             const long long m = tile_pix0 + i;
             return m < p.M ? m : -1;
-        };
-        // one 4-cout quad of one accumulator tile -> (ReLU, convert) -> staging row (the bias is already in)
-        auto stage_quad = [&](const f32x16 &t, int ci, int g, int srow) {
-            float q4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) q4[j] = p.relu ? fmaxf(t[4 * g + j], 0.f) : t[4 * g + j];
-            char *d = stg + srow * SSTRIDE + (ci * 32 + 8 * g + 4 * hh) * ES;
-            *(uint2 *)d = make_uint2(pack2<DT>(q4[0], q4[1]), pack2<DT>(q4[2], q4[3]));
         };
         if (p.out && !(TDRN_PP_ABLATE & 4)) {
             // Round 5: straight from the registers.  Group c = 4 ci + g is the 16-byte chunk c of my pixel's span of 128 couts; lane r32 has its
@@ -390,48 +378,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PPParams p)
             }
         }
         if constexpr (POOL && TW != 0) if (p.out_pool) {
-            // fused MaxPool2d(2,2) on the RAW accumulators (max commutes with the monotonic bias+ReLU applied at
-            // staging): the partner row is my other pixel tile (TW = 32) or lane^16 (TW = 16); the partner column is
-            // lane^1.  Even-x lanes of the top row hold the result.
+            // fused MaxPool2d(2,2) on the RAW accumulators (max commutes with the monotonic bias + ReLU + rounding applied afterwards), straight
+            // from the registers as in conv3x3_patch.hip (round 5): the partner row is my other pixel fragment (TW = 32) or lane ^ 16
+            // (v_permlane16_swap), the partner column lane ^ 1 (DPP); the window's 2 / 4 lanes then hold the same maxima and store different
+            // chunk pairs of the same pooled pixel (v_permlane32_swap pairs -> dwordx4).
+            typedef short pk_s2 __attribute__((ext_vector_type(2)));
+            const pk_s2 relu_lo = p.relu ? pk_s2{0, 0} : pk_s2{(short)-32768, (short)-32768};
+            auto pkr = [&](float a, float b) -> unsigned {
+                return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, pack2<DT>(a, b)), relu_lo));
+            };
             const int PW = p.W >> 1;
-            constexpr int npool = TW == 32 ? 16 : 8;    // pooled pixels per pixel tile
-            const bool holder = (r32 & 1) == 0 && (TW == 32 || r32 < 16);
-            const int prow_l = r32 >> 1;
+            const int cbase = n0 + grp * BNH;
+            constexpr int NPAIR = 2 * WC;                       // 8 chunk pairs per pixel
+            constexpr int NDUP = TW == 32 ? 2 : 4;              // lanes holding the same window
+            const int sel = TW == 32 ? (r32 & 1) : ((r32 & 1) | ((r32 >> 3) & 2));
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 if (TW == 32 && pt == 1) break;
+                const int i = cw * 64 + pt * 32 + r32;
+                const long long gpool = (long long)((tile_row0 + (i >> LGTW)) >> 1) * PW + ((tile_x0 + (i & (TW - 1))) >> 1);
+                char *row = p.out_pool + ((size_t)gpool * p.Cs + cbase) * ES;
+                // round rd: chunk pairs rd * NDUP .. rd * NDUP + NDUP - 1, one per lane of the window (only their maxima are computed now:
+                // 16 packed registers live at a time instead of 64)
 #pragma unroll
-                for (int ci = 0; ci < WC; ++ci)
+                for (int rd = 0; rd < NPAIR / NDUP; ++rd) {
+                    uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = acc[ci][pt][e];
-                        if (TW == 32) v = fmaxf(v, acc[ci][1][e]);
-                        else v = fmaxf(v, __shfl_xor(v, 16, 64));
-                        v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));     // lane ^ 1: a DPP quad permute, not an LDS round trip
-                        acc[ci][pt][e] = v;
-                    }
-#pragma unroll 1
-                for (int rd = 0; rd < (npool + SROWS - 1) / SROWS; ++rd) {
-                    if (holder && prow_l / SROWS == rd) {
+                    for (int d = 0; d < NDUP; ++d) {
+                        const int pr = rd * NDUP + d, ci = pr >> 1, g0 = 2 * (pr & 1);
+                        float m[8];
 #pragma unroll
-                        for (int ci = 0; ci < WC; ++ci)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) stage_quad(acc[ci][pt], ci, g, prow_l % SROWS);
-                    }
-                    PP_LGKM0();
-                    __builtin_amdgcn_wave_barrier();
-                    const int rows_here = (npool - rd * SROWS) < SROWS ? (npool - rd * SROWS) : SROWS;
-#pragma unroll
-                    for (int k = 0; k < SROWS / RPI; ++k) {
-                        const int row = my_row + k * RPI;
-                        if (row < rows_here && my_c < p.Cout) {
-                            const int pl = rd * SROWS + row;            // pooled pixel within this pixel tile
-                            const int i0 = cw * 64 + pt * 32 + 2 * pl;  // top-left pixel of the 2x2 window
-                            const long long gpool = (long long)((tile_row0 + (i0 >> LGTW)) >> 1) * PW + ((tile_x0 + (i0 & (TW - 1))) >> 1);
-                            *(u32x4 *)(p.out_pool + ((size_t)gpool * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SSTRIDE + my_ch * 16);
+                        for (int j = 0; j < 8; ++j) {
+                            float v = acc[ci][pt][4 * g0 + j];
+                            if (TW == 32) {
+                                v = fmaxf(v, acc[ci][1][4 * g0 + j]);
+                            } else {
+                                float va = v, vb = v;
+                                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(va), "+v"(vb));
+                                v = fmaxf(va, vb);
+                            }
+                            m[j] = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
                         }
+                        const bool mine = sel == d;
+                        const unsigned ax = pkr(m[0], m[1]), ay = pkr(m[2], m[3]), bx = pkr(m[4], m[5]), by = pkr(m[6], m[7]);
+                        a.x = mine ? ax : a.x; a.y = mine ? ay : a.y; b.x = mine ? bx : b.x; b.y = mine ? by : b.y;
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    const int mypr = rd * NDUP + sel;
+                    auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+                    auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+                    if (cbase + (2 * mypr + hh) * 8 < p.Cout)
+                        *(u32x4 *)(row + (2 * mypr + hh) * 16) = u32x4{rx[0], ry[0], rx[1], ry[1]};
                 }
             }
         }
@@ -761,9 +757,9 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
 {
     const int mode = pp_conv_supported(a);
     if (!mode) return TDRN_E_UNSUPPORTED;
-    // the two pooled layers of a trunk stay on conv3x3_patch.hip: with the pooled epilogue in, this kernel's 256-register
-    // budget spills inside the step loop (the POOL = true instantiation is kept in the source for the day it does not)
-    if (out_pool) return TDRN_E_UNSUPPORTED;
+    // pooled layers (conv3_3: the pooled output only): the POOL instantiation with the register-only pooled epilogue (round 5; with the staged
+    // epilogue its 256-register budget spilled inside the step loop).  Flat tiles have no pooled variant.
+    if (out_pool && (mode < 0 || (a.H & 1) || (a.W & 1))) return TDRN_E_UNSUPPORTED;
     PPParams p;
     p.in = (const char *)a.in; p.w = (const char *)a.w; p.zero = (const char *)a.zero_page; p.bias = a.bias;
     p.out = (char *)a.out; p.out_pool = (char *)out_pool;
@@ -808,7 +804,10 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
     }
 #define PP_LAUNCH(DT)                                                                                                  \
     do {                                                                                                               \
-        if (tw == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 0, false>), dim3(grid), dim3(512), 0, s, p);           \
+        if (out_pool) {                                                                                                \
+            if (tw == 32) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 32, true>), dim3(grid), dim3(512), 0, s, p);     \
+            else hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 16, true>), dim3(grid), dim3(512), 0, s, p);               \
+        } else if (tw == 0) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 0, false>), dim3(grid), dim3(512), 0, s, p);    \
         else if (tw == 32) hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 32, false>), dim3(grid), dim3(512), 0, s, p);   \
         else hipLaunchKernelGGL((conv3x3_pp_kernel<DT, 16, false>), dim3(grid), dim3(512), 0, s, p);                  \
     } while (0)
