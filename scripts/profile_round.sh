@@ -9,15 +9,15 @@
 #   trace_graph/          the same of `bench.py --graph 1`                  (the hipGraph REPLAY: what the bench line times)
 #   pmc_fetch/ pmc_write/ rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE           (HBM-side traffic per dispatch)
 #   pmc_sq/               rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE              (wave cycles, waits, matrix-pipe busy, LDS conflicts, clock)
-OUT=${1:-gpurun_out/r04_final}
+OUT=${1:-gpurun_out/r05_final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --per-op --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 > $OUT/bench_per_op.json 2> $OUT/per_op.txt
-COMMON="--steps 5 --warmup 3 --reps 3 --no-cpu-baseline --no-parity --no-modes --stream 0"
+COMMON="--steps 5 --warmup 3 --reps 3 --no-cpu-baseline --no-parity --no-modes --stream 0 --in-flight 1"      # (kernel durations: one pipeline; bench.json above is the default two-in-flight line)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $COMMON --graph 0 > $OUT/bench_traced.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_graph -- python3 bench.py $COMMON --graph 1 > $OUT/bench_traced_graph.json 2> $OUT/trace_graph.err
-PM="--steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 --no-detect"
+PM="--steps 2 --warmup 1 --reps 1 --no-cpu-baseline --no-parity --no-modes --stream 0 --graph 0 --no-detect --in-flight 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PM > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $PM > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PM > /dev/null 2> $OUT/pmc_sq.err

@@ -38,7 +38,7 @@ def forwards(rows):
     out, cur = [], None
     for r in rows:
         n = short(r["Kernel_Name"])
-        if n.startswith("first_conv") or (n.startswith("conv3x3_patch_kernel") and n.rstrip().endswith("true>")):     # (16-bit plans: the first conv lives in conv1_2's loader)
+        if n.startswith("first_conv") or (n.startswith("conv3x3_patch_kernel") and n.rstrip().endswith("true>")) or (n.startswith("conv3x3_ws_kernel") and ", true," in n):     # (16-bit plans: the first conv lives in conv1_2's loader / producers)
             cur = []
             out.append(cur)
         if cur is not None and "tdrn" in r["Kernel_Name"]:
@@ -72,7 +72,7 @@ def main():
             for r in f:
                 n = short(r["Kernel_Name"])
                 # (one family: the loader/consumer kernel and the all-waves-compute kernel share the 3x3 layers of a plan)
-                fam = "patch" if (n.startswith("conv3x3_patch") or n.startswith("conv3x3_pp")) else ("igemm" if n.startswith("conv_igemm") else n.split("<")[0])
+                fam = "patch" if (n.startswith("conv3x3_patch") or n.startswith("conv3x3_pp") or n.startswith("conv3x3_ws")) else ("igemm" if n.startswith("conv_igemm") else n.split("<")[0])
                 acc[(fam, seen[fam])].append(value(r))
                 seen[fam] += 1
         return {k: sum(v) / len(v) for k, v in acc.items()}
@@ -83,7 +83,7 @@ def main():
     graph_line = None
     if trg_rows:
         trg_rows = [r for r in trg_rows if "tdrn" in r["Kernel_Name"]]
-        fam_rows = [r for r in trg_rows if short(r["Kernel_Name"]).startswith(("conv3x3_patch", "conv3x3_pp"))]
+        fam_rows = [r for r in trg_rows if short(r["Kernel_Name"]).startswith(("conv3x3_patch", "conv3x3_pp", "conv3x3_ws"))]
         # the last 3/4 of the dispatches: the timed loop (warm-up and capture passes come first)
         fam_rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         fam_rows = fam_rows[len(fam_rows) // 4:]
@@ -194,7 +194,7 @@ def main():
             print("conv3x3 family in the hipGraph REPLAY (kernel trace of what bench.py times): %.1f us per launch over %d launches = %.1f TFLOP/s = %.3f of peak"
                   % (gus, gn, patch_gflop / n_patch / gus * 1e3, patch_gflop / n_patch / gus * 1e3 / PEAK))
             with open(os.path.join(dst, "graph_replay_family.txt"), "w") as f:
-                f.write("conv3x3 family (conv3x3_patch_kernel + conv3x3_pp_kernel), rocprofv3 --kernel-trace of `bench.py --graph 1`: %.2f us per launch over %d launches "
+                f.write("conv3x3 family (conv3x3_patch_kernel + conv3x3_pp_kernel + conv3x3_ws_kernel), rocprofv3 --kernel-trace of `bench.py --graph 1`: %.2f us per launch over %d launches "
                         "= %.1f TFLOP/s = %.4f of 2500\n" % (gus, gn, patch_gflop / n_patch / gus * 1e3, patch_gflop / n_patch / gus * 1e3 / PEAK))
 
 
