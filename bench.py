@@ -584,7 +584,7 @@ def main_other(args):
                       "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
                       "copy_streams_picked": (fs.calibration or {}).get("picked"),
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
-                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s % in-flight): one hipGraph per slot = tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
+                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): one hipGraph per slot = tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL)}
         KEEP_ALIVE.append(fs)
 
@@ -960,7 +960,7 @@ def main():
                       "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
                       "copy_streams_picked": (fs.calibration or {}).get("picked"),
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
-                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s % in-flight): one hipGraph per slot = tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
+                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): one hipGraph per slot = tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL),
                       "note": "the resident figure (`value`) starts from fp32 frames already preprocessed in HBM; this one includes the resize kernel and both copies"}
         KEEP_ALIVE.append(fs)

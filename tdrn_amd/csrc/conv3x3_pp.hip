@@ -797,7 +797,7 @@ int launch_conv3x3_pp(const ConvArgs &a, void *out_pool, hipStream_t s)
     p.sk_slab = nullptr; p.sk_flag = nullptr;
     p.status = a.status; p.fault = a.fault_handoff; p.poll_max = a.fault_handoff ? (1u << 10) : (1u << 20);
     // (grid == 256: every workgroup of the launch is resident at once, see the poll in begin_acc)
-    if (a.sk_ws && conv_pp_sk_enabled() && !(a.kdisable & 2) && grid == 256 && p.items > 256 && p.items % 256 != 0) {
+    if (a.sk_ws && conv_pp_sk_enabled() && !(a.kdisable & 2) && (grid == 256 || (cap > 0 && grid == cap && cap >= 192)) && p.items > grid && p.items % grid != 0) {
         p.sk_flag = (unsigned *)a.sk_ws;
         p.sk_slab = (float *)((char *)a.sk_ws + 1024);
         if (!a.sk_flags_zero) TDRN_HIP_TRY(hipMemsetAsync(p.sk_flag, 0, 1024, s));

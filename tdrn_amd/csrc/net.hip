@@ -174,7 +174,7 @@ struct tdrn_net {
     bool pp_sk_planned = false;          // some main-lane conv may use conv3x3_pp.hip's chained split
     int fuse_first = -1;                 // index of the conv whose patch loader computes the first conv itself (16-bit modes), or -1
     int x_t = -1;                        // fp32 (3, S, S) workspace tensor: the net input when the caller hands uint8 planes to a plan whose first conv reads fp32
-    int late_side = 1, side_grid = 0;
+    int late_side = 1, side_grid = 0, main_grid = 0;
     bool use_lanes = true, lanes_ready = false, deform_split = true;
     int plan_error = TDRN_OK;
     int splitk_ref_batch = 32;          // split-K factors are planned for this batch (the benchmark's) and used for every batch (TDRN_SPLITK_REF)
@@ -745,6 +745,7 @@ struct tdrn_net {
         if (cfg.plan_flags & TDRN_PLAN_NO_LATE_SIDE) late_side = 0;
         if (const char *e = getenv("TDRN_LATE_SIDE")) late_side = atoi(e);
         if (const char *e = getenv("TDRN_SIDE_GRID")) side_grid = atoi(e);
+        if (const char *e = getenv("TDRN_MAIN_GRID")) main_grid = atoi(e);      // experiment: cap the persistent grids of the main lane (CUs left to the other step in flight)
         if (const char *rb = getenv("TDRN_SPLITK_REF")) splitk_ref_batch = atoi(rb) > 0 ? atoi(rb) : 32;
         // split-K per layer from its geometry only (at the reference batch, 32 unless TDRN_SPLITK_REF says otherwise), so that a frame's arithmetic never
         // depends on the batch it travels in; the partial slabs live in a per-lane region of the workspace
@@ -1336,6 +1337,7 @@ struct tdrn_net {
                     ConvArgs a;
                     conv_args(o, a);
                     if (lane != 0) a.max_wgs = side_grid;
+                    else if (main_grid > 0) a.max_wgs = main_grid;
                     if (o.lane == 0 && pp_sk_planned) {
                         a.sk_ws = tail + kTailCtl;
                         a.sk_flags_zero = true;
