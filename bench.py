@@ -817,7 +817,7 @@ def main():
     # The default schedule (round 5): TWO steps in flight.  Step k replays resident batch k % NB on pipeline (k % NB) % NF; the timed
     # region is still K steps between two device-wide synchronisations.  `roofline` below comes from single-pipeline profiling
     # passes of engine 0 (a launch's duration with another step's kernels beside it says nothing about the kernel).
-    NF = max(1, args.in_flight) if (args.graph and NS == 1) else 1
+    NF = max(1, args.in_flight) if ((args.graph or os.environ.get("TDRN_BENCH_EAGER_IN_FLIGHT")) and NS == 1) else 1
     while NB % NF:
         NF -= 1
 
@@ -831,7 +831,7 @@ def main():
                 r = e.forward(xin)
                 return r["conf"] if args.no_detect else d.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
             return one_step
-        fl = InFlight(make_step, engine, xb, n=NF, graph=True)
+        fl = InFlight(make_step, engine, xb, n=NF, graph=bool(args.graph))
         KEEP_ALIVE.append(fl)
         return fl
     if NF > 1:

@@ -241,6 +241,8 @@ typedef struct {
 #define TDRN_PLAN_NO_DW_SLIDE   2048 /* depthwise 3x3 layers on the one-row strip kernel instead of the sliding-window one (same bits)       */
 #define TDRN_PLAN_DW_SLIDE_ALL  4096 /* ... the sliding-window kernel (8-row segments) at every batch, also where it leaves CUs idle       */
 #define TDRN_PLAN_NO_CONV_WS    8192 /* the Cin = 64 layers (conv1_2, conv2_1) stay on conv3x3_patch.hip instead of the weight-stationary conv3x3_ws.hip */
+#define TDRN_PLAN_NO_YGEMM_V2  16384 /* transform-then-sample heads: the transform on the round-3 schedule of ygemm_k256 (two barriers per tile, stores behind the
+                                       multiply phase) instead of the round-5 one (deform.hip ygemm_k256_v2_kernel); same bits                    */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 

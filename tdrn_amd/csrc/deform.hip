@@ -580,7 +580,19 @@ struct YGemmMulti {
     YGemmParams p[4];
     int block_start[5];            // workgroups of problem i: [block_start[i], block_start[i+1]); inside: cg = local % cgs, part = local / cgs
     int n;
+#ifdef TDRN_YG_STAMP
+    unsigned *stamps;              // diagnostics build only (make EXTRA=-DTDRN_YG_STAMP): [workgroup][wave][6] cycle sums / tile count
+#endif
 };
+#ifdef TDRN_YG_STAMP
+#define YG_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(); unsigned st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define YG_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += (unsigned)(t_ - st_t); st_t = t_; } while (0)
+#define YG_STAMP_FLUSH do { st_acc[5] = (unsigned)nt; if (lane == 0) for (int k_ = 0; k_ < 6; ++k_) mp.stamps[((size_t)blockIdx.x * 8 + wave) * 6 + k_] = st_acc[k_]; } while (0)
+#else
+#define YG_STAMP_DECL
+#define YG_STAMP(k) do { } while (0)
+#define YG_STAMP_FLUSH do { } while (0)
+#endif
 
 template <typename DT, int CT>
 __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k256_kernel(const YGemmMulti mp)
@@ -616,21 +628,34 @@ __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k2
     int nt = (p.M + TP - 1) / TP - t0;
     nt = nt < p.tiles_per_part ? nt : p.tiles_per_part;
     if (nt <= 0) return;
+    YG_STAMP_DECL
+
     // staging: a tile = 32 rows x 512 B = 16 pieces of 1 KiB (2 rows each); wave w issues pieces PPW w .. PPW w + PPW - 1.
     // LDS image linear; the 16-byte chunk c of row r is stored at chunk position c ^ (r & 31) (swizzle on the SOURCE address)
+    // The LDS-DMA goes out as inline asm (round 5): behind the builtin hipcc put an `s_waitcnt vmcnt(0)` in front of the first LDS read
+    // of every tile -- it cannot tell the DMA's LDS writes from the tile being read -- which drained the NEXT tile's pieces (issued a few
+    // instructions earlier) and every store in flight: the double buffer never overlapped anything (stamps: 2800 of a tile's 5500
+    // cycles in the multiply phase, 16 MFMAs).  Completion is waited for by hand below, as before.
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)smem;
     auto stage = [&](int t, int buf) {
+        const long long mb = (long long)(t0 + t) * TP;   // (wave-uniform)
+        const char *sb = p.x + (size_t)mb * 512;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int piece = PPW * wave + j;
             const int row = 2 * piece + (lane >> 5), cpos = lane & 31;
-            long long m = (long long)(t0 + t) * TP + row;
-            if (m >= p.M) m = p.M - 1;                   // (rows past the end re-read the last pixel; their results are not stored)
-            const char *src = p.x + (size_t)m * 512 + ((cpos ^ (row & 31)) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(smem + buf * TBYTES + piece * 1024), 16, 0, 0);
+            int r = row;
+            if (mb + r >= p.M) r = (int)(p.M - 1 - mb);  // (rows past the end re-read the last pixel; their results are not stored)
+            const unsigned voff = (unsigned)(r * 512 + ((cpos ^ (row & 31)) << 4));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voff), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(smem_lds + buf * TBYTES + piece * 1024))
+                         : "memory");
         }
     };
     stage(0, 0);
+    YG_STAMP(0);                                         // prologue: my weight fragments
     // 16-byte store instructions this wave issues per full tile (wave-uniform)
     constexpr int NSTR = 32 * 32 / NT;                   // row-major layout: 32 rows x 32 chunks / threads
     int nst_prev = NSTR;
@@ -658,8 +683,10 @@ __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k2
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        YG_STAMP(1);                                     // landing of tile t (and of the stores before it)
         __builtin_amdgcn_s_barrier();                    // (raw: __syncthreads() would drain the piece just issued)
         asm volatile("" ::: "memory");
+        YG_STAMP(2);                                     // barrier
         f32x16 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -688,8 +715,10 @@ __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k2
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);              // my LDS reads of tile t have returned, my staging writes are done ...
+        YG_STAMP(3);                                     // reads + MFMAs + staging writes
         __builtin_amdgcn_s_barrier();                    // ... and everybody's: tile t's buffer may be refilled, the image is whole
         asm volatile("" ::: "memory");
+        YG_STAMP(2);                                     // barrier
         if (p.taps > 0) {
             // tap-major Y: [tap][pixel][80 columns].  A tap's 160-byte rows of consecutive pixels are contiguous, so the four bilinear
             // corners of the sampling launch are two runs of 320 bytes and neighbouring output pixels share their cache lines.
@@ -714,7 +743,168 @@ __global__ __launch_bounds__(CT == 1 ? 512 : 256, CT == 1 ? 4 : 2) void ygemm_k2
         }
         // (the next tile's staging writes come behind the barrier at the top of the next iteration: no wave can still be
         // reading this image then)
+        YG_STAMP(4);                                     // issue of the stores
     }
+    YG_STAMP_FLUSH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ygemm_k256_v2 (round 5; tap-major Y only): the same tiles, fragments, K order and stores as the kernel above -- every Y element has the
+// same bits -- in a schedule in which nothing waits for anything it does not need:
+//  * ONE barrier per tile.  Behind it: tile t has landed (every wave waited for its own LDS-DMA pieces), the staged image of tile t - 1 is
+//    whole, nobody reads tile t - 1's input buffer any more.  The period that follows issues the LDS-DMA of tile t + 1 (a whole period to
+//    land), multiplies tile t and -- between its MFMAs -- carries tile t - 1's image from LDS to Y (two images, used alternately).
+//  * the pixel fragments are read THREE MFMAs ahead (the compiler's own order was one ahead: a 16-long chain of read -> MFMA at ~110
+//    cycles a link); the 16 swizzled read offsets are one XOR with a literal each instead of 16 registers.
+// Stamps of the first version (diagnostics build, ticks per tile and wave): landing 830, barriers 870, reads + MFMAs + staging 2800
+// (with hipcc's vmcnt(0) in front of the first read, see `stage` above), store issue 1040.
+// ---------------------------------------------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(512, 4) void ygemm_k256_v2_kernel(const YGemmMulti mp)
+{
+    int prob = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < mp.n && (int)blockIdx.x >= mp.block_start[i]) prob = i;
+    const YGemmParams &p = mp.p[prob];
+    const int local_blk = (int)blockIdx.x - mp.block_start[prob];
+    const int ncg = p.N / 256;
+    constexpr int TP = 32;                               // pixels per tile
+    constexpr int TBYTES = TP * 512;                     // 16 KiB
+    constexpr int SROW = 512 + 16;                       // staging row: 256 columns + a 16-byte pad (bank spread)
+    constexpr int SBYTES = TP * SROW;
+    constexpr int PPW = 2;                               // LDS-DMA pieces per wave and tile
+    __shared__ __attribute__((aligned(16))) char smem[2 * TBYTES + 2 * SBYTES];
+    char *const sst = smem + 2 * TBYTES;                 // two output images [pixel][256 columns]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int part = local_blk / ncg, cg = local_blk - part * ncg;
+    const int col0 = cg * 256 + wave * 32;
+    u32x4 wf[16];                                        // fragment kk = channels [16kk + 8hh, +8) of column col0 + r32
+    {
+        const char *wr = p.w + ((size_t)(col0 + r32) * 256 + 8 * hh) * 2;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wf[kk] = *(const u32x4 *)(wr + kk * 32);
+    }
+    const int t0 = part * p.tiles_per_part;
+    int nt = (p.M + TP - 1) / TP - t0;
+    nt = nt < p.tiles_per_part ? nt : p.tiles_per_part;
+    if (nt <= 0) return;
+    YG_STAMP_DECL
+
+    const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)smem;
+    auto stage = [&](int t, int buf) {                   // (as above: 32 rows x 512 B, chunk c of row r at position c ^ (r & 31))
+        const long long mb = (long long)(t0 + t) * TP;
+        const char *sb = p.x + (size_t)mb * 512;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int piece = PPW * wave + j;
+            const int row = 2 * piece + (lane >> 5), cpos = lane & 31;
+            int r = row;
+            if (mb + r >= p.M) r = (int)(p.M - 1 - mb);
+            const unsigned voff = (unsigned)(r * 512 + ((cpos ^ (row & 31)) << 4));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voff), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(smem_lds + buf * TBYTES + piece * 1024))
+                         : "memory");
+        }
+    };
+    // the store trips of this wave: trip j carries (tap, 6-pixel group) number it = wave + 8 j of the slice's 3 x 6 from the image to Y
+    // (lane = 10 * pixel + chunk -> 960 contiguous bytes of Y); three per tile for waves 0 and 1, two for the others
+    const int px = lane / 10, kch = lane - 10 * px;
+    unsigned t_lds[3], t_off[3];
+    int t_on[3], t_pg[3], nst = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int it = wave + 8 * j, sgi = it / 6, pg = it - sgi * 6, tap = cg * 3 + sgi, row = pg * 6 + px;
+        t_on[j] = it < 18 && tap < p.taps;               // (wave-uniform)
+        t_pg[j] = pg;
+        const bool ok = lane < 60 && row < TP && t_on[j];
+        t_lds[j] = ok ? (unsigned)(row * SROW + (sgi * 10 + kch) * 16) : 0u;
+        t_off[j] = ok ? (unsigned)(((size_t)tap * p.M + (size_t)t0 * TP + row) * 160 + kch * 16) : 0u;     // (taps x M x 160 < 4 GiB: ygemm_fill)
+        nst += t_on[j] ? 1 : 0;
+    }
+    auto carry_read = [&](int j, int img) -> u32x4 { return *(const u32x4 *)(sst + img * SBYTES + t_lds[j]); };
+    auto carry_store = [&](int j, int rows, const u32x4 &v) {
+        if (t_on[j] && rows > 0) {                       // (rows == 0: the first period, nothing to carry yet)
+            if (lane < 60 && t_pg[j] * 6 + px < rows) *(u32x4 *)(p.y + (size_t)t_off[j]) = v;
+            t_off[j] += TP * 160;
+        }
+    };
+    // my swizzled read offsets: fragment kk of pixel r32 sits at r32 * 512 + (((2 kk + hh) ^ r32) << 4) = rd0 ^ (kk << 5)
+    unsigned rd0 = (unsigned)(r32 * 512 + (((hh ^ r32) & 1) << 4) + ((r32 & 30) << 4));
+    const unsigned sw = (unsigned)(r32 * SROW + (wave * 32 + 4 * hh) * 2);
+    stage(0, 0);
+    YG_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) stage(t + 1, buf ^ 1);           // (its last readers passed the barrier that ended period t - 1)
+        YG_STAMP(1);
+        const long long left = (long long)p.M - (long long)(t0 + t - 1) * TP;
+        const int rows_prev = t > 0 ? (left < TP ? (int)left : TP) : 0;      // rows of tile t - 1 (0: nothing to carry yet)
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const char *ab = smem + buf * TBYTES;
+        u32x4 a[4], sv;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            asm volatile("" : "+v"(rd0));
+            a[kk] = *(const u32x4 *)(ab + (rd0 ^ (unsigned)(kk << 5)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            if (kk + 3 < 16) {
+                asm volatile("" : "+v"(rd0));
+                a[(kk + 3) & 3] = *(const u32x4 *)(ab + (rd0 ^ (unsigned)((kk + 3) << 5)));
+            }
+            if (kk == 1 || kk == 6 || kk == 11) sv = carry_read((kk - 1) / 5, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            MmaD<DT>::run(wf[kk], a[kk & 3], acc);
+            if (kk == 5 || kk == 10 || kk == 15) carry_store((kk - 5) / 5, rows_prev, sv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane = pixel r32; register e = column (e & 3) + 8 (e >> 2) + 4 hh of my 32 columns -> the image of tile t
+        {
+            const unsigned sa = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)sst + (unsigned)(buf * SBYTES) + sw;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 v = make_uint2(pack2<DT>(acc[4 * g], acc[4 * g + 1]), pack2<DT>(acc[4 * g + 2], acc[4 * g + 3]));
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(v), "n"(16 * g) : "memory");
+            }
+        }
+        YG_STAMP(3);
+        // my image rows are written, my reads of tile t have returned; tile t + 1's pieces (older than this period's stores) have landed
+        if (t + 1 < nt) {
+            switch (t > 0 ? nst : 0) {
+                case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        YG_STAMP(4);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        YG_STAMP(2);
+    }
+    {   // the last tile's image
+        const long long left = (long long)p.M - (long long)(t0 + nt - 1) * TP;
+        const int rows = left < TP ? (int)left : TP;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const u32x4 v = carry_read(j, (nt - 1) & 1);
+            carry_store(j, rows, v);
+        }
+    }
+    YG_STAMP_FLUSH;
 }
 
 int ygemm_supported(int Cin, int ycols, int dtype) { return dtype != TDRN_F32 && Cin == 256 && ycols % 256 == 0; }
@@ -746,7 +936,7 @@ static int ygemm_fill(const YGemmProblem &q, int dtype, YGemmParams &p, int &blo
     return TDRN_OK;
 }
 
-int launch_ygemm_multi(const YGemmProblem *pr, int n, int dtype, hipStream_t s)
+int launch_ygemm_multi(const YGemmProblem *pr, int n, int dtype, hipStream_t s, int kdisable)
 {
     if (!pr || n < 1 || n > 4) return TDRN_E_ARG;
     YGemmMulti mp;
@@ -767,11 +957,48 @@ int launch_ygemm_multi(const YGemmProblem *pr, int n, int dtype, hipStream_t s)
     if (mp.n == 0) return TDRN_OK;
     for (int i = mp.n; i < 4; ++i) { mp.p[i] = mp.p[0]; mp.block_start[i + 1] = mp.block_start[mp.n]; }
     dim3 grid((unsigned)mp.block_start[mp.n]);
+#ifdef TDRN_YG_STAMP
+    static unsigned *stamps = nullptr;
+    static int calls = 0;
+    const size_t nst = (size_t)grid.x * 8 * 6;
+    if (!stamps) TDRN_HIP_TRY(hipMalloc((void **)&stamps, 4096 * 8 * 6 * sizeof(unsigned)));
+    TDRN_HIP_TRY(hipMemsetAsync(stamps, 0, nst * sizeof(unsigned), s));
+    mp.stamps = stamps;
+    struct Report {
+        hipStream_t s; size_t n; unsigned *d; YGemmMulti &mp; int *calls;
+        ~Report() {
+            if (++*calls != 5) return;                   // (one report, of a launch that is not the first)
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned> h(n);
+            (void)hipMemcpy(h.data(), d, n * sizeof(unsigned), hipMemcpyDeviceToHost);
+            for (int pr = 0; pr < mp.n; ++pr) {
+                double a[5] = {0, 0, 0, 0, 0}, tiles = 0, waves = 0;
+                for (int b = mp.block_start[pr]; b < mp.block_start[pr + 1]; ++b)
+                    for (int w = 0; w < 8; ++w) {
+                        const unsigned *q = &h[((size_t)b * 8 + w) * 6];
+                        if (!q[5]) continue;
+                        for (int k = 0; k < 5; ++k) a[k] += q[k];
+                        tiles += q[5]; waves += 1;
+                    }
+                if (waves == 0) continue;
+                fprintf(stderr, "yg_stamp problem %d M %d blocks %d tiles/wg %.1f | per wave: prologue %.0f | per tile: landing %.0f barriers %.0f mma+stage %.0f stores %.0f (ticks of s_memtime)\n",
+                        pr, mp.p[pr].M, mp.block_start[pr + 1] - mp.block_start[pr], tiles / waves, a[0] / waves, a[1] / tiles, a[2] / tiles, a[3] / tiles, a[4] / tiles);
+            }
+        }
+    } report{s, nst, stamps, mp, &calls};
+#endif
     static int ct = -1;
     // CT = 2 (four waves x 64 columns: half the LDS reads per output) measured 337-344 us against 332-334 us for the pair of deform
     // launches (round 4, interleaved): the transform is not bound by its LDS reads; the round-3 shape stays the default
     if (ct < 0) { const char *e = getenv("TDRN_YGEMM_CT"); ct = e ? atoi(e) : 1; }
-    if (ct == 1) {
+    static int v2 = -1;
+    if (v2 < 0) { const char *e = getenv("TDRN_YGEMM_V2"); v2 = e ? atoi(e) : 1; }
+    bool tapmajor = true;
+    for (int i = 0; i < mp.n; ++i) tapmajor = tapmajor && mp.p[i].taps > 0;
+    if (v2 && !(kdisable & 128) && tapmajor && ct == 1) {
+        if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_v2_kernel<bf16_t>), grid, dim3(512), 0, s, mp);
+        else hipLaunchKernelGGL((ygemm_k256_v2_kernel<f16_t>), grid, dim3(512), 0, s, mp);
+    } else if (ct == 1) {
         if (dtype == TDRN_BF16) hipLaunchKernelGGL((ygemm_k256_kernel<bf16_t, 1>), grid, dim3(512), 0, s, mp);
         else hipLaunchKernelGGL((ygemm_k256_kernel<f16_t, 1>), grid, dim3(512), 0, s, mp);
     } else {

@@ -193,7 +193,7 @@ int launch_deform_sample_multi(const DeformArgs *args, const void *const *y, con
 int ygemm_supported(int Cin, int ycols, int dtype);
 int launch_ygemm(const void *x, const void *w, void *y, long long M, int N, int ycs, int dtype, hipStream_t s, int taps = 0);   // taps > 0: Y tap-major [taps][M][80]
 struct YGemmProblem { const void *x, *w; void *y; long long M; int N, ycs, taps; };
-int launch_ygemm_multi(const YGemmProblem *pr, int n, int dtype, hipStream_t s);      // up to 4 problems (pyramid levels) in one launch
+int launch_ygemm_multi(const YGemmProblem *pr, int n, int dtype, hipStream_t s, int kdisable = 0);      // up to 4 problems (pyramid levels) in one launch
 
 // ---------------------------------------------------------------------------------------------
 // Detect (detect.hip)

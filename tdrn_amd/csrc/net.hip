@@ -681,7 +681,7 @@ struct tdrn_net {
         kdisable = ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PP) ? 1 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PP_SK) ? 2 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_YGEMM_V2) ? 128 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
@@ -1517,7 +1517,7 @@ struct tdrn_net {
                                 }
                                 ts_y[i] = ybuf; ts_cs[i] = d.y_cols;
                             }
-                            if (rc == TDRN_OK && n_yq > 0) rc = launch_ygemm_multi(yq, n_yq, cfg.dtype, s);
+                            if (rc == TDRN_OK && n_yq > 0) rc = launch_ygemm_multi(yq, n_yq, cfg.dtype, s, kdisable);
                             if (rc == TDRN_OK) rc = launch_deform_sample_multi(ca, ts_y, ts_cs, n_dargs, s, ts_tap_major);
                           }
                         n_dargs = 0;

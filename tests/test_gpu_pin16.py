@@ -423,7 +423,8 @@ def test_kernel_choice_never_changes_a_bit(dtype):
         # (round 5: + the weight-stationary conv3x3_ws.hip on conv1_2 / conv2_1 -- with the first conv fused into its producers, and
         # from a materialised conv1_1 -- against conv3x3_patch.hip's loader / consumer kernel on the same layers)
         for flags in (_lib.PLAN_NO_CONV_PP, _lib.PLAN_NO_PP_SK, _lib.PLAN_NO_CONV_PP | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_CONV_WS,
-                      _lib.PLAN_NO_CONV_WS | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_FUSE_FIRST):
+                      _lib.PLAN_NO_CONV_WS | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_FUSE_FIRST,
+                      _lib.PLAN_NO_YGEMM_V2):        # (+ the transform of the deformable heads on its round-3 schedule)
             other, _ = _build(VGG[0], args, dtype=dtype, flags=flags)
             got = _outputs(other, x)
             assert len(got) == len(want)
