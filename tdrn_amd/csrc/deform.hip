@@ -793,15 +793,15 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_v2_kernel(const YGemmMulti 
     YG_STAMP_DECL
 
     const unsigned smem_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)smem;
-    auto stage = [&](int t, int buf) {                   // (as above: 32 rows x 512 B, chunk c of row r at position c ^ (r & 31))
-        const long long mb = (long long)(t0 + t) * TP;
-        const char *sb = p.x + (size_t)mb * 512;
+    // (as above: 32 rows x 512 B, chunk c of row r at position c ^ (r & 31); `sb` = the tile's first row, `avail` = rows of the tensor
+    // from there on -- rows past the end re-read the last one, their results are not stored; kept incrementally: the 64-bit index
+    // arithmetic of the first version was ~60 scalar instructions per tile in front of two DMA instructions)
+    auto stage = [&](const char *sb, int avail, int buf) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int piece = PPW * wave + j;
             const int row = 2 * piece + (lane >> 5), cpos = lane & 31;
-            int r = row;
-            if (mb + r >= p.M) r = (int)(p.M - 1 - mb);
+            const int r = row < avail ? row : avail - 1;
             const unsigned voff = (unsigned)(r * 512 + ((cpos ^ (row & 31)) << 4));
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -826,26 +826,33 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_v2_kernel(const YGemmMulti 
         nst += t_on[j] ? 1 : 0;
     }
     auto carry_read = [&](int j, int img) -> u32x4 { return *(const u32x4 *)(sst + img * SBYTES + t_lds[j]); };
+    __attribute__((address_space(1))) char *ybase = (__attribute__((address_space(1))) char *)p.y;
+    asm volatile("" : "+s"(ybase));                      // (kept in scalar registers: re-loaded from the kernel arguments in front of every store,
+                                                         // it came back through lgkmcnt and drained the LDS reads in flight)
     auto carry_store = [&](int j, int rows, const u32x4 &v) {
         if (t_on[j] && rows > 0) {                       // (rows == 0: the first period, nothing to carry yet)
-            if (lane < 60 && t_pg[j] * 6 + px < rows) *(u32x4 *)(p.y + (size_t)t_off[j]) = v;
+            if (lane < 60 && t_pg[j] * 6 + px < rows) *(__attribute__((address_space(1))) u32x4 *)(ybase + (size_t)t_off[j]) = v;
             t_off[j] += TP * 160;
         }
     };
     // my swizzled read offsets: fragment kk of pixel r32 sits at r32 * 512 + (((2 kk + hh) ^ r32) << 4) = rd0 ^ (kk << 5)
     unsigned rd0 = (unsigned)(r32 * 512 + (((hh ^ r32) & 1) << 4) + ((r32 & 30) << 4));
     const unsigned sw = (unsigned)(r32 * SROW + (wave * 32 + 4 * hh) * 2);
-    stage(0, 0);
+    const char *sb = p.x + (size_t)t0 * TP * 512;        // (wave-uniform) first row of the tile to stage next
+    int avail = p.M - t0 * TP;                           // rows from there to the end of the tensor (> 0 for every tile staged)
+    stage(sb, avail, 0);
+    sb += TBYTES; avail -= TP;
     YG_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) stage(t + 1, buf ^ 1);           // (its last readers passed the barrier that ended period t - 1)
+        if (t + 1 < nt) stage(sb, avail, buf ^ 1);       // (its last readers passed the barrier that ended period t - 1)
+        sb += TBYTES; avail -= TP;                       // (avail is now the row count from tile t + 2 on: tile t - 1 had avail + 3 TP)
         YG_STAMP(1);
-        const long long left = (long long)p.M - (long long)(t0 + t - 1) * TP;
-        const int rows_prev = t > 0 ? (left < TP ? (int)left : TP) : 0;      // rows of tile t - 1 (0: nothing to carry yet)
+        const int left = avail + 3 * TP;
+        const int rows_prev = t > 0 ? (left < TP ? left : TP) : 0;           // rows of tile t - 1 (0: nothing to carry yet)
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -896,8 +903,8 @@ __global__ __launch_bounds__(512, 4) void ygemm_k256_v2_kernel(const YGemmMulti 
         YG_STAMP(2);
     }
     {   // the last tile's image
-        const long long left = (long long)p.M - (long long)(t0 + nt - 1) * TP;
-        const int rows = left < TP ? (int)left : TP;
+        const int left = p.M - (t0 + nt - 1) * TP;
+        const int rows = left < TP ? left : TP;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const u32x4 v = carry_read(j, (nt - 1) & 1);
