@@ -292,6 +292,28 @@ def _timed(stepper, steps, reps, tdist, torch, dev):
     return out
 
 
+def _choose_launch(graph_flight, make_eager, steps, frames, tdist, torch, dev):
+    """Two ways to put the same two pipelines in flight: one hipGraph replay per step, or the step's launches issued eagerly from
+    this thread (the reference's own drivers launch eagerly).  On ROCm 7.2 two replays on two streams hardly overlap
+    (scripts/dev/inflight_timeline.py: step k + 1 starts when step k ends) while eager pipelines do -- if their main lanes sit on
+    different hardware queues, which InFlight.pick_streams settles by a short calibration.  Which way is faster depends on the host
+    (it has to keep up with ~70 launches per step), so both are timed here over the same steps and the timed region uses the faster;
+    the line says which (`config.launch`, `launch_calibration_frames_per_s`).  Returns (flight, mode, calibration)."""
+    eager = make_eager()
+    for k in range(4):
+        eager.launch(k)                                  # (lanes, workspaces, LDS attributes of the clone exist before the calibration)
+    eager.pick_streams()
+    cal, n = {}, max(8, min(steps, 40))
+    for name_, fl_ in (("hipGraph replay", graph_flight), ("eager", eager), ("hipGraph replay", graph_flight), ("eager", eager)):
+        for k in range(4):
+            fl_.launch(k)
+        cal[name_] = min(cal.get(name_, 1e9), min(_timed(fl_.launch, n, 1, tdist, torch, dev)) / n)
+    table = {k_: round(frames / v_, 2) for k_, v_ in cal.items()}
+    if cal["eager"] < cal["hipGraph replay"] * 0.995:
+        return eager, "eager", table
+    return graph_flight, "hipGraph replay", table
+
+
 def _family_table(stats_prod, stats_solo, mult=1):
     solo_ms = {s["name"]: s["ms"] for s in stats_solo}
     return {s["name"]: {"ms": round(s["ms"] * mult, 4), "ms_single_stream": round(solo_ms.get(s["name"], 0.0) * mult, 4), "launches": s["launches"] * mult,
@@ -408,6 +430,7 @@ def main_other(args):
         name = "dualrefinedet_mobilenet multihead"
 
     NF = 1
+    launch_mode, launch_cal = ("hipGraph replay" if args.graph else "eager"), None
     if args.graph and not trn and args.in_flight > 1:
         # config 4: two steps in flight, as the headline configuration (tdrn_amd.engine.InFlight)
         from tdrn_amd.engine import InFlight
@@ -424,6 +447,12 @@ def main_other(args):
             return step_of
         flight = InFlight(make_step, eng, xb, n=NF, graph=True)
         KEEP_ALIVE.append(flight)
+        if args.launch == "auto":
+            def make_eager():
+                fl_ = InFlight(make_step, eng, xb, n=NF, graph=False)
+                KEEP_ALIVE.append(fl_)
+                return fl_
+            flight, launch_mode, launch_cal = _choose_launch(flight, make_eager, args.steps, world * frames_per_step, tdist, torch, dev)
         step = flight.launch
         engines = [(e_, 1) for e_ in flight.engines]
     elif args.graph:
@@ -557,7 +586,7 @@ def main_other(args):
         NSL = 3
         while NSL % NF:
             NSL += 1
-        fs = FrameStream([eng] + [eng.clone() for _ in range(NF - 1)] if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL)
+        fs = FrameStream([eng] + [eng.clone() for _ in range(NF - 1)] if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL, graph=launch_mode != "eager")
         rng = np.random.RandomState(7)
         for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -582,9 +611,10 @@ def main_other(args):
         want = fs.eager(fs.pinned_in(0).to(dev)).cpu()
         stream_blk = {"frames_per_s": round(world * B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
                       "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
-                      "copy_streams_picked": (fs.calibration or {}).get("picked"),
+                      "copy_streams_picked": (fs.calibration or {}).get("picked"), "pipeline_streams_picked": (fs.pipeline_calibration or {}).get("picked"),
+                      "launch": "hipGraph replay" if fs.graph else "eager",
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
-                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): one hipGraph per slot = tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
+                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): per slot (one hipGraph, or the same launches issued eagerly: `launch`) tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL)}
         KEEP_ALIVE.append(fs)
 
@@ -601,7 +631,7 @@ def main_other(args):
                                                        ("%d clips x 4 frames (per step: 1 static + 4 temporal forwards of %d frames + 4 Detect calls, frame by frame as evaluate_trn.py)" % (B, B))) if trn else "batch %d" % B,
                        "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)") + ("" if NCLS == 21 else "; %d classes (not BASELINE's 21; the GFLOP figures stay the 21-class ones)" % NCLS),
                    "global_batch": world * frames_per_step, "parallelism": "%s-sharded x%d, no per-frame collective" % ("clip" if trn else "frame", world),
-                   "launch": "hipGraph replay" if args.graph else "eager", "resident_batches": NB, "steps_in_flight": NF},
+                   "launch": launch_mode, "launch_calibration_frames_per_s": launch_cal, "resident_batches": NB, "steps_in_flight": NF},
         "repetitions": {"n": len(reps), "reported": "median", "timed_steps_total": len(reps) * args.steps, "ms_per_step_min": round(reps[0] / args.steps * 1e3, 4), "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
         "fps_per_gpu": round(fps / world, 2), "forward_only_ms_per_step": round(fwd_ms, 4), "forward_tflops": round(gflop_step / fwd_ms, 2),
         "build": build, "roofline": roofline, "kernels": kernels,
@@ -709,6 +739,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the box / score error and detection-agreement blocks (oracle forwards on the host)")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other precisions")
     ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
+    ap.add_argument("--launch", choices=["auto", "fixed"], default="auto",
+                    help="headline configuration, two steps in flight: auto = time hipGraph replay AND eager launches briefly and run the timed region with the faster (reported in config.launch); fixed = what --graph says")
     ap.add_argument("--graph", type=int, default=1, help="1: the step (forward + Detect) is one captured hipGraph replay; 0: eager launches")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="whole steps in flight (tdrn_amd.engine.InFlight): resident batch j runs on pipeline j %% N (own engine handle, workspace, "
@@ -821,7 +853,7 @@ def main():
     while NB % NF:
         NF -= 1
 
-    def in_flight_stepper(engine):
+    def in_flight_stepper(engine, as_graph):
         from tdrn_amd.engine import InFlight
 
         def make_step(e):
@@ -831,15 +863,9 @@ def main():
                 r = e.forward(xin)
                 return r["conf"] if args.no_detect else d.forward(r["odm_loc"], r["conf"], pri, arm_loc_data=r["arm_loc"], scale=scale)
             return one_step
-        fl = InFlight(make_step, engine, xb, n=NF, graph=bool(args.graph))
+        fl = InFlight(make_step, engine, xb, n=NF, graph=as_graph)
         KEEP_ALIVE.append(fl)
         return fl
-    if NF > 1:
-        flight = in_flight_stepper(eng)
-        step = flight.launch
-        engines = flight.engines
-    else:
-        step = make_stepper(eng, det) if NS == 1 else eager_step
 
     def timed(stepper, steps, reps):
         """`reps` repetitions of the K-step loop, each bracketed by barrier + synchronize on both sides and reduced with
@@ -856,6 +882,17 @@ def main():
             out.append(tdist.max_over_ranks(time.perf_counter() - t0, dev))
         return out
 
+    launch_mode, launch_cal = ("hipGraph replay" if (args.graph and NS == 1) else "eager"), None
+    if NF > 1:
+        flight = in_flight_stepper(eng, bool(args.graph))
+        if args.graph and args.launch == "auto":
+            flight, launch_mode, launch_cal = _choose_launch(flight, lambda: in_flight_stepper(eng, False), args.steps, world * B, tdist, torch, dev)
+        elif not args.graph:
+            launch_mode = "eager"
+        step = flight.launch
+        engines = flight.engines
+    else:
+        step = make_stepper(eng, det) if NS == 1 else eager_step
     for k in range(args.warmup):
         step(k)
     reps = sorted(timed(step, args.steps, max(1, args.reps)))
@@ -933,7 +970,7 @@ def main():
         while NSL % NF:
             NSL += 1
         fs_engines = [eng] + [eng.clone() for _ in range(NF - 1)]                     # NF steps in flight here too (slot s on pipeline s % NF)
-        fs = FrameStream(fs_engines if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL)     # one pinned batch per slot: the slots' batches cycle
+        fs = FrameStream(fs_engines if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL, graph=launch_mode != "eager")     # one pinned batch per slot: the slots' batches cycle; launched the way the headline chose
         rng = np.random.RandomState(7)
         for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -958,9 +995,10 @@ def main():
         want = fs.eager(fs.pinned_in(0).to(dev)).cpu()
         stream_blk = {"frames_per_s": round(world * B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
                       "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
-                      "copy_streams_picked": (fs.calibration or {}).get("picked"),
+                      "copy_streams_picked": (fs.calibration or {}).get("picked"), "pipeline_streams_picked": (fs.pipeline_calibration or {}).get("picked"),
+                      "launch": "hipGraph replay" if fs.graph else "eager",
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
-                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): one hipGraph per slot = tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
+                      "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): per slot (one hipGraph, or the same launches issued eagerly: `launch`) tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL),
                       "note": "the resident figure (`value`) starts from fp32 frames already preprocessed in HBM; this one includes the resize kernel and both copies"}
         KEEP_ALIVE.append(fs)
@@ -973,7 +1011,15 @@ def main():
             print("bench.py: timing the %s mode" % dtm, file=sys.stderr, flush=True)
             net.set_compute_dtype(dtm)
             e2 = net.engine(dev)
-            st2 = in_flight_stepper(e2).launch if NF > 1 else make_stepper(e2, Detect(NCLS, 0, 200, 0.01, 0.45))
+            if NF > 1:
+                fl2 = in_flight_stepper(e2, launch_mode != "eager")      # (the launch mode the headline chose)
+                if launch_mode == "eager":
+                    for k in range(4):
+                        fl2.launch(k)
+                    fl2.pick_streams()
+                st2 = fl2.launch
+            else:
+                st2 = make_stepper(e2, Detect(NCLS, 0, 200, 0.01, 0.45))
             k_steps = max(5, min(args.steps, 10 if dtm == "fp32" else args.steps))
             for k in range(3):
                 st2(k)
@@ -1000,11 +1046,13 @@ def main():
                                    (args.size, args.size, args.dtype, B, "" if args.no_detect else " + Detect(top_k 200, conf 0.01, nms 0.45)",
                                     "" if NCLS == 21 else ", %d classes (not BASELINE's 21)" % NCLS),
                        "global_batch": world * B, "parallelism": "frame-sharded x%d, no per-frame collective" % world,
-                       "launch": "hipGraph replay" if (args.graph and NS == 1) else "eager",
+                       "launch": launch_mode,
+                       "launch_calibration_frames_per_s": launch_cal,
+                       "eager_stream_calibration": (getattr(flight, "stream_calibration", None) or {}).get("picked") if launch_mode == "eager" else None,
                        "resident_batches": NB,
                        "steps_in_flight": NF,
-                       "schedule": ("%d steps in flight: resident batch j replays on pipeline j %% %d (own engine handle, workspace, HIP stream, hipGraph; one weight blob); "
-                                    "K steps between two device-wide synchronisations" % (NF, NF)) if NF > 1 else "one step at a time"},
+                       "schedule": ("%d steps in flight: resident batch j runs on pipeline j %% %d (own engine handle, workspace, HIP stream%s; one weight blob); "
+                                    "K steps between two device-wide synchronisations" % (NF, NF, ", hipGraph" if launch_mode != "eager" else ", launched eagerly")) if NF > 1 else "one step at a time"},
             "repetitions": {"n": len(reps), "reported": "median", "timed_steps_total": len(reps) * args.steps, "ms_per_step_min": round(reps[0] / args.steps * 1e3, 4),
                             "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
             "fps_per_gpu": round(fps / world, 2),

@@ -356,6 +356,43 @@ class InFlight(object):
             else:
                 self.calls.append(None)
         self._eager_out = [None] * len(self.batches)
+        self.stream_calibration = None
+
+    def pick_streams(self, candidates=4, steps=6):
+        """Eager pipelines only: choose the HIP streams the pipelines launch on by a short calibration.
+
+        ROCm maps HIP streams onto a few in-order hardware queues (4 by default) in creation order and does not say which.  Two
+        pipelines whose main lanes share a queue run one after the other whatever the streams say (a queue is a FIFO: step k + 1's
+        first kernel sits behind every launch of step k's main lane); main lanes that share queues with the OTHER pipeline's side
+        lanes lose less; the best pairing measured +7 % over the worst (profiles/r05_experiments.md "Hardware queues").  So: a few
+        candidate streams (consecutive streams of torch's pool sit on consecutive queues), every ordered pair timed over `steps`
+        steps, the best pair kept.  ~16 x steps steps on whatever the resident batches hold; results are unaffected (the same
+        launches in the same per-pipeline order).  Returns {"i,j": ms per step} and keeps the best pair."""
+        import time
+        if self.graph or self.n != 2:
+            return None
+        cands = [torch.cuda.Stream(self.dev) for _ in range(candidates)]
+        nb = len(self.batches)
+
+        def timed(i, j, n):
+            torch.cuda.synchronize(self.dev)
+            self.streams = [cands[i], cands[j]]
+            for k in range(2):
+                self.launch(k)
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for k in range(n):
+                self.launch(k % nb)
+            torch.cuda.synchronize(self.dev)
+            return (time.perf_counter() - t0) / n
+        timings = {(i, j): timed(i, j, steps) for i in range(candidates) for j in range(candidates) if i != j}
+        for key in sorted(timings, key=timings.get)[:3]:
+            timings[key] = timed(key[0], key[1], 3 * steps)
+        best = min(timings, key=timings.get)
+        torch.cuda.synchronize(self.dev)
+        self.streams = [cands[best[0]], cands[best[1]]]
+        self.stream_calibration = {"ms_per_step": {"%d,%d" % k: round(v * 1e3, 3) for k, v in timings.items()}, "picked": "%d,%d" % best}
+        return self.stream_calibration
 
     def launch(self, k):
         j = k % len(self.batches)

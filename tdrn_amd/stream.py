@@ -42,7 +42,7 @@ class Ticket(int):
 class FrameStream(object):
     """slots x (pinned input, device input, captured step, device output, pinned output), used cyclically."""
 
-    def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=3, calibrate=True):
+    def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=3, calibrate=True, graph=True):
         if slots < AHEAD + 1:
             raise ValueError("FrameStream needs at least %d slots (it copies %d batches ahead)" % (AHEAD + 1, AHEAD))
         # `engine`: one NetEngine, or a list of them (engine.clone(): own workspace and lanes, shared weights) = that many STEPS IN
@@ -72,7 +72,13 @@ class FrameStream(object):
             return one_step
         steps = [make_step(e, d) for e, d in zip(engines, detects)]
         self._fn = steps[0]
+        self._steps = steps
+        # graph=False: the step's launches are issued eagerly on the pipeline's stream (the reference's drivers launch eagerly too).  On
+        # ROCm 7.2 two hipGraph replays on two streams hardly overlap (scripts/dev/inflight_timeline.py) while eagerly launched
+        # pipelines do; the host has to keep up (~70 launches per step)
+        self.graph = bool(graph)
         self._extra_streams = [torch.cuda.Stream(dev) for _ in range(NP - 1)]
+        self._pipe_streams = None                         # eager mode: the pipelines' streams picked by calibration (_pick_pipeline_streams)
         self.host_in = [torch.empty((batch, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(slots)]
         self.dev_in = [torch.zeros((batch, H0, W0, 3), dtype=torch.uint8, device=dev) for _ in range(slots)]
         # lazily created resources (lanes, LDS attributes, workspaces) before any capture
@@ -86,7 +92,7 @@ class FrameStream(object):
         torch.cuda.synchronize(dev)
         self.host_out = [torch.empty(tuple(probe.shape), dtype=probe.dtype).pin_memory() for _ in range(slots)]
         self.graphs, self.dev_out = [], []
-        for s in range(slots):
+        for s in range(slots if self.graph else 0):
             g = torch.cuda.CUDAGraph()
             # one private pool per PIPELINE: a pipeline's steps run one after another on its stream, so their intermediates may
             # share memory (each slot's OUTPUT stays live and is never aliased); steps of different pipelines run concurrently
@@ -94,6 +100,8 @@ class FrameStream(object):
                 out = steps[s % NP](self.dev_in[s])
             self.graphs.append(g)
             self.dev_out.append(out)
+        if not self.graph:
+            self.dev_out = [torch.empty_like(probe) for _ in range(slots)]     # (the step's result is copied here: 2.7 MB on the device)
         self._in_stream = torch.cuda.Stream(dev)
         self._out_stream = torch.cuda.Stream(dev)
         self.ev_in = [torch.cuda.Event() for _ in range(slots)]        # slot's frames are on the device
@@ -105,8 +113,39 @@ class FrameStream(object):
         self._k = 0
         self._step_of = [-1] * slots                                   # the pipeline step whose result a slot holds (or will hold)
         self.calibration = None
+        self.pipeline_calibration = None
         if calibrate:
+            if not self.graph and NP == 2:
+                self._pick_pipeline_streams()
             self._pick_streams()
+
+    def _pick_pipeline_streams(self, candidates=4, steps=6):
+        """Eager mode, two pipelines: which hardware queues the two main lanes sit on decides how much of a step overlaps the next
+        (engine.InFlight.pick_streams: +7 % between the worst and the best pairing); every ordered pair of a few candidate streams is
+        timed over `steps` pipeline steps, the best kept."""
+        import time
+        cands = [torch.cuda.Stream(self.dev) for _ in range(candidates)]
+
+        def timed(i, j, n):
+            torch.cuda.synchronize(self.dev)
+            self._pipe_streams = [cands[i], cands[j]]
+            self.prime()
+            for _ in range(2):
+                self.run()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                self.run()
+            torch.cuda.synchronize(self.dev)
+            return (time.perf_counter() - t0) / n
+        timings = {(i, j): timed(i, j, steps) for i in range(candidates) for j in range(candidates) if i != j}
+        for k in sorted(timings, key=timings.get)[:3]:
+            timings[k] = timed(k[0], k[1], 3 * steps)
+        best = min(timings, key=timings.get)
+        torch.cuda.synchronize(self.dev)
+        self._pipe_streams = [cands[best[0]], cands[best[1]]]
+        self.pipeline_calibration = {"ms_per_step": {"%d,%d" % k: round(v * 1e3, 3) for k, v in timings.items()}, "picked": "%d,%d" % best}
+        self.prime()
 
     def _pick_streams(self, candidates=4, steps=10):
         """ROCm maps HIP streams onto a few in-order hardware queues (4 by default) in creation order, and HIP does not say
@@ -176,10 +215,17 @@ class FrameStream(object):
         s = self._k % self.slots
         self._copy_in((self._k + AHEAD) % self.slots)
         p = s % self.pipelines
-        cur = torch.cuda.current_stream(self.dev) if p == 0 else self._extra_streams[p - 1]
+        if self._pipe_streams is not None:
+            cur = self._pipe_streams[p]
+        else:
+            cur = torch.cuda.current_stream(self.dev) if p == 0 else self._extra_streams[p - 1]
         with torch.cuda.stream(cur):
             cur.wait_event(self.ev_in[s])
-            self.graphs[s].replay()
+            if self.graph:
+                self.graphs[s].replay()
+            else:
+                cur.wait_event(self.ev_out[s])           # (the slot's previous detections have left its output buffer)
+                self.dev_out[s].copy_(self._steps[p](self.dev_in[s]))
             self.ev_step[s].record(cur)
         with torch.cuda.stream(self._out_stream):
             self._out_stream.wait_event(self.ev_step[s])

@@ -991,19 +991,37 @@ def test_two_steps_in_flight_equal_one_at_a_time():
                     assert torch.equal(fl.output(j), want[j]), (graph, turn, j)
         fl.sync()
         fl.check()
+        if not graph:
+            # the eager pipelines' streams chosen by calibration (bench.py's default launch mode when it is the faster one): every
+            # ordered pair of candidate streams is run; afterwards the results are still the same bits
+            cal = fl.pick_streams(candidates=3, steps=NB)
+            assert cal and cal["picked"] in cal["ms_per_step"] and len(cal["ms_per_step"]) == 6
+            for turn in range(2):
+                for k in range(NB):
+                    fl.launch(turn * NB + k)
+            fl.sync()
+            for j in range(NB):
+                assert torch.equal(fl.output(j), want[j]), ("picked streams", j)
+            fl.check()
+        else:
+            assert fl.pick_streams() is None             # (graph pipelines: the streams are part of the capture)
     assert (want[0][..., 0] > 0).any()
 
 
-def test_frame_stream_with_two_pipelines_equals_unstreamed():
-    """FrameStream given two engines (slot s on pipeline s % 2): same results as the unstreamed step, slot after slot."""
+@pytest.mark.parametrize("graph", [True, False])
+def test_frame_stream_with_two_pipelines_equals_unstreamed(graph):
+    """FrameStream given two engines (slot s on pipeline s % 2): same results as the unstreamed step, slot after slot -- as one hipGraph
+    per slot, and with the steps launched eagerly on pipeline streams picked by calibration (the streamed twin of InFlight.pick_streams)."""
     from tdrn_amd.stream import FrameStream
     net, _ = _build("dualrefinedet_vggbn", (320, 21, 1024, 1, True, True))
     net.set_compute_dtype("bf16")
     eng = net.engine(DEV)
     pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
     B, slots, n = 4, 4, 11
-    fs = FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots, calibrate=False)
+    fs = FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots, calibrate=not graph, graph=graph)
     assert fs.pipelines == 2
+    if not graph:
+        assert fs.pipeline_calibration["picked"] in fs.pipeline_calibration["ms_per_step"] and fs.calibration is not None
     rng = np.random.RandomState(12)
     feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)) for _ in range(n)]
     fs.prime(feeds[:2])
@@ -1019,8 +1037,9 @@ def test_frame_stream_with_two_pipelines_equals_unstreamed():
     fs.drain()
     for k, got in enumerate(results):
         assert torch.equal(got, fs.eager(feeds[k].to(DEV)).cpu()), k
-    with pytest.raises(ValueError):
-        FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=3, calibrate=False)
+    if graph:
+        with pytest.raises(ValueError):
+            FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=3, calibrate=False)
 
 
 @pytest.mark.parametrize("model,args,dtype,batches", [
