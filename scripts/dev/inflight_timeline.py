@@ -42,6 +42,21 @@ def make_step(e):
     return one
 
 
+def dummy_streams(n):
+    """n HIP streams nobody uses: shifts the round-robin assignment of the NEXT streams to the hardware queues (experiment)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    for _ in range(n):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0
+        KEEP.append(h)
+
+
+KEEP = []
+dummy_streams(int(os.environ.get("SHIFT_A", "0")))
+eng.forward(xb[0])                                       # engine 0's side lanes exist from here on
+torch.cuda.synchronize()
+dummy_streams(int(os.environ.get("SHIFT_B", "0")))
 fl = InFlight(make_step, eng, xb, n=NP, graph=os.environ.get("MODE", "graph") != "eager")
 for k in range(3 * NB):
     fl.launch(k)
@@ -56,7 +71,7 @@ for k in range(100):
     fl.launch(k)
 fl.sync()
 dt = (time.perf_counter() - t0) / 100
-print("NP %d NB %d %s queues %s flags %s grid %s: %.3f ms per step = %.0f frames/s" % (NP, NB, os.environ.get("MODE", "graph"), os.environ.get("GPU_MAX_HW_QUEUES", "4"), os.environ.get("FLAGS", "0"), os.environ.get("TDRN_MAIN_GRID", "-"), dt * 1e3, B / dt))
+print("shift %s/%s NP %d NB %d %s queues %s flags %s grid %s: %.3f ms per step = %.0f frames/s" % (os.environ.get("SHIFT_A", "0"), os.environ.get("SHIFT_B", "0"), NP, NB, os.environ.get("MODE", "graph"), os.environ.get("GPU_MAX_HW_QUEUES", "4"), os.environ.get("FLAGS", "0"), os.environ.get("TDRN_MAIN_GRID", "-"), dt * 1e3, B / dt))
 if SHOW <= 0:
     sys.exit(0)
 E = lambda: torch.cuda.Event(enable_timing=True)
