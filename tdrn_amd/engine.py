@@ -368,16 +368,17 @@ class InFlight(object):
         candidate streams (consecutive streams of torch's pool sit on consecutive queues), every ordered pair timed over `steps`
         steps, the best pair kept.  ~16 x steps steps on whatever the resident batches hold; results are unaffected (the same
         launches in the same per-pipeline order).  Returns {"i,j": ms per step} and keeps the best pair."""
+        import itertools
         import time
-        if self.graph or self.n != 2:
+        if self.graph or self.n < 2 or self.n > candidates:
             return None
         cands = [torch.cuda.Stream(self.dev) for _ in range(candidates)]
         nb = len(self.batches)
 
-        def timed(i, j, n):
+        def timed(sel, n):
             torch.cuda.synchronize(self.dev)
-            self.streams = [cands[i], cands[j]]
-            for k in range(2):
+            self.streams = [cands[i] for i in sel]
+            for k in range(self.n):
                 self.launch(k)
             torch.cuda.synchronize(self.dev)
             t0 = time.perf_counter()
@@ -385,13 +386,13 @@ class InFlight(object):
                 self.launch(k % nb)
             torch.cuda.synchronize(self.dev)
             return (time.perf_counter() - t0) / n
-        timings = {(i, j): timed(i, j, steps) for i in range(candidates) for j in range(candidates) if i != j}
+        timings = {sel: timed(sel, steps) for sel in itertools.permutations(range(candidates), self.n)}
         for key in sorted(timings, key=timings.get)[:3]:
-            timings[key] = timed(key[0], key[1], 3 * steps)
+            timings[key] = timed(key, 3 * steps)
         best = min(timings, key=timings.get)
         torch.cuda.synchronize(self.dev)
-        self.streams = [cands[best[0]], cands[best[1]]]
-        self.stream_calibration = {"ms_per_step": {"%d,%d" % k: round(v * 1e3, 3) for k, v in timings.items()}, "picked": "%d,%d" % best}
+        self.streams = [cands[i] for i in best]
+        self.stream_calibration = {"ms_per_step": {",".join(map(str, k)): round(v * 1e3, 3) for k, v in timings.items()}, "picked": ",".join(map(str, best))}
         return self.stream_calibration
 
     def launch(self, k):
