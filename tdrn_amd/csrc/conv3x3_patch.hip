@@ -63,6 +63,9 @@ struct PatchParams {
 #ifdef TDRN_PATCH_STAMP
     unsigned *stamps;              // diagnostics build only: [workgroup][wave][8] cycle sums (s_memtime), see the launcher
 #endif
+#ifdef TDRN_PATCH_WGTIME
+    unsigned long long *wgt;       // diagnostics build only (make EXTRA=-DTDRN_PATCH_WGTIME): [workgroup][2] s_memrealtime at its first / last instruction
+#endif
 };
 
 // In-kernel cycle stamps of a diagnostics build (make EXTRA=-DTDRN_PATCH_STAMP; never in the product): where do the
@@ -178,6 +181,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nchunks = p.Cin / CK;
+#ifdef TDRN_PATCH_WGTIME
+    if (threadIdx.x == 0) p.wgt[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- work distribution: each XCD (blockIdx % 8) owns a contiguous range of items so that cout
     // siblings of a pixel tile and neighbouring tiles share its L2.  This workgroup runs items
@@ -891,6 +897,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         }
     }
     STAMP_FLUSH;
+#ifdef TDRN_PATCH_WGTIME
+    if (threadIdx.x == 0) p.wgt[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -910,11 +919,43 @@ int patch_conv_supported(const ConvArgs &a)
     return 0;
 }
 
-template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p, hipStream_t s)
+template <typename DT, int BN> static int launch_patch_cfg(const PatchParams &p_in, hipStream_t s)
 {
+    PatchParams p = p_in;
     // a multiple of 8 workgroups (the item split is per XCD); surplus workgroups find no item and exit
     int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
     if (p.max_wgs > 0 && grid > p.max_wgs) grid = p.max_wgs;
+#ifdef TDRN_PATCH_WGTIME
+    // diagnostics build: when did every workgroup of launch number TDRN_WGTIME_CALL (and the 17 after it) start and end?  (s_memrealtime,
+    // 100 MHz; never inside a stream capture: the report synchronises)
+    static unsigned long long *wgt = nullptr;
+    static long calls = 0, want = -1;
+    if (!wgt) TDRN_HIP_TRY(hipMalloc((void **)&wgt, 256 * 2 * sizeof(unsigned long long)));
+    if (want < 0) { const char *e = getenv("TDRN_WGTIME_CALL"); want = e ? atol(e) : 2000; }
+    p.wgt = wgt;
+    const bool report = calls >= want && calls < want + 18;
+    ++calls;
+    if (report) TDRN_HIP_TRY(hipMemsetAsync(wgt, 0, 256 * 2 * sizeof(unsigned long long), s));
+    struct Report {
+        bool on; hipStream_t s; int grid; const PatchParams &p; unsigned long long *d;
+        ~Report() {
+            if (!on) return;
+            (void)hipStreamSynchronize(s);
+            unsigned long long h[512];
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            int n = 0;
+            for (int i = 0; i < grid; ++i) if (h[2 * i]) { t0 = h[2 * i] < t0 ? h[2 * i] : t0; t1 = h[2 * i + 1] > t1 ? h[2 * i + 1] : t1; ++n; }
+            double late = 0, busy = 0, worst = 0, e_min = 1e18; int n5 = 0, n20 = 0;
+            for (int i = 0; i < grid; ++i) if (h[2 * i]) {
+                const double d0 = (h[2 * i] - t0) * 0.01, b = (h[2 * i + 1] - h[2 * i]) * 0.01, e = (h[2 * i + 1] - t0) * 0.01;
+                late += d0; busy += b; worst = d0 > worst ? d0 : worst; e_min = e < e_min ? e : e_min; n5 += d0 > 5; n20 += d0 > 20;
+            }
+            fprintf(stderr, "wgtime %dx%d Cin %d Cout %d items %d grid %d: span %.1f us, workgroup busy mean %.1f us, first end at %.1f us; start later than the first: mean %.1f us, max %.1f us, > 5 us: %d, > 20 us: %d of %d\n",
+                    p.H, p.W, p.Cin, p.Cout, p.items, grid, (t1 - t0) * 0.01, busy / n, e_min, late / n, worst, n5, n20, n);
+        }
+    } rep{report, s, grid, p, wgt};
+#endif
     if constexpr (BN == 64 && sizeof(DT) == 2) {
         if (p.fx) {
             if (p.tw != 32 || p.n_tiles != 1 || p.H % 16) return TDRN_E_UNSUPPORTED;
