@@ -30,7 +30,7 @@ eng = net.engine(dev)
 pri = PriorBox(mb_cfg["VOC_320"]).forward().to(dev)
 engines = [eng] + [eng.clone() for _ in range(NP - 1)]
 NSL = 4
-fs = FrameStream(engines if NP > 1 else eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NSL, calibrate=os.environ.get("CAL", "1") != "0", graph=os.environ.get("MODE", "graph") != "eager")
+fs = FrameStream(engines if NP > 1 else eng, Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=NSL, calibrate=os.environ.get("CAL", "1") != "0", graph=os.environ.get("MODE", "graph") != "eager", zero_copy_out=os.environ.get("ZC", "0") != "0", copy_in=os.environ.get("CI", "stream"))
 rng = np.random.RandomState(7)
 for sl in range(NSL):
     fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -66,12 +66,20 @@ def run_instrumented(k_show):
         a.record(cur)
         if fs.graph:
             fs.graphs[s].replay()
+        elif fs.zero_copy_out:
+            fs._steps[p](fs.dev_in[s], out=fs.host_out[s])
         else:
             fs.dev_out[s].copy_(fs._steps[p](fs.dev_in[s]))
         fs.ev_step[s].record(cur)
+        if fs.zero_copy_out:
+            fs.ev_out[s].record(cur)
         b.record(cur)
     rec.append(("step %d (pipeline %d)" % (fs._k, p), fs._k, a, b))
     a, b = E(), E()
+    if fs.zero_copy_out:
+        fs._step_of[s] = fs._k
+        fs._k += 1
+        return
     with torch.cuda.stream(fs._out_stream):
         fs._out_stream.wait_event(fs.ev_step[s])
         a.record(fs._out_stream)
@@ -94,7 +102,9 @@ for _ in range(60):
     fs.run()
 fs.drain()
 dt = (time.perf_counter() - t0) / 60
-print("streamed: %.3f ms per step = %.0f frames/s" % (dt * 1e3, B / dt))
+print("streamed (%s, copy-in %s, zero-copy out %s, NP %d): %.3f ms per step = %.0f frames/s" % ("graph" if fs.graph else "eager", fs.copy_in, fs.zero_copy_out, NP, dt * 1e3, B / dt))
+if fs.copy_in == "own" or SHOW <= 0:
+    sys.exit(0)                                          # (the instrumented replica below knows the copy-in stream only)
 base = E()
 fs.prime()
 for _ in range(8):

@@ -21,10 +21,13 @@ class Detect(object):
         self._ws = None
         self.last_counts = None
 
-    def forward(self, loc_data, conf_data, prior_data, arm_loc_data=None, scale=None, feature=None):
+    def forward(self, loc_data, conf_data, prior_data, arm_loc_data=None, scale=None, feature=None, out=None):
         """loc (B,P,4), conf (B*P,C), priors (P,4), arm_loc (B,P,4)|None, scale 4-vector (default
         [320]*4 like detection.py:25).  `feature` is accepted and ignored (test_video.py:115 passes
-        it).  Returns (B, C, top_k, 5) rows [score, x1, y1, x2, y2] on the inputs' device."""
+        it).  Returns (B, C, top_k, 5) rows [score, x1, y1, x2, y2] on the inputs' device.
+        `out` (not in the reference): a preallocated (B, C, top_k, 5) fp32 tensor the rows are written into -- on the device, or in
+        PINNED host memory (the kernel's only use of it is one coalesced write per (image, class) row, so the detections then cross
+        PCIe as part of the launch and no device-to-host copy follows: tdrn_amd/stream.py)."""
         _lib.require_cuda(loc_data, "loc_data")
         dev = loc_data.device
         B, P, Cn = loc_data.size(0), prior_data.size(0), self.num_classes
@@ -49,7 +52,13 @@ class Detect(object):
         nb = lib.tdrn_detect_workspace_bytes(B, P, Cn, self.top_k)
         if self._ws is None or self._ws.numel() < nb or self._ws.device != dev:
             self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        out = torch.empty((B, Cn, self.top_k, 5), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((B, Cn, self.top_k, 5), dtype=torch.float32, device=dev)
+        else:
+            if tuple(out.shape) != (B, Cn, self.top_k, 5) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous fp32 tensor of shape %s" % ((B, Cn, self.top_k, 5),))
+            if not (out.is_cuda and out.device == dev) and not (out.device.type == "cpu" and out.is_pinned()):
+                raise ValueError("out must live on %s or in pinned host memory" % (dev,))
         counts = torch.empty((B, Cn), dtype=torch.int32, device=dev)
         fn, sarg = (lib.tdrn_detect_dev_scale, _lib.ptr(scale_d)) if scale_d is not None else (lib.tdrn_detect, scale_h)
         _lib.check(fn(_lib.ptr(loc), _lib.ptr(conf), _lib.ptr(pri), _lib.ptr(arm), sarg, B, P, Cn,

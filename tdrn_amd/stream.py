@@ -42,7 +42,7 @@ class Ticket(int):
 class FrameStream(object):
     """slots x (pinned input, device input, captured step, device output, pinned output), used cyclically."""
 
-    def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=3, calibrate=True, graph=True):
+    def __init__(self, engine, detect, priors, batch, frame_hw=(375, 500), mean=(104.0, 117.0, 123.0), scale=None, slots=3, calibrate=True, graph=True, zero_copy_out=False, copy_in="stream"):
         if slots < AHEAD + 1:
             raise ValueError("FrameStream needs at least %d slots (it copies %d batches ahead)" % (AHEAD + 1, AHEAD))
         # `engine`: one NetEngine, or a list of them (engine.clone(): own workspace and lanes, shared weights) = that many STEPS IN
@@ -62,13 +62,25 @@ class FrameStream(object):
         size = engines[0].cfg.size
         scale = scale if scale is not None else [float(W0), float(H0), float(W0), float(H0)]
 
+        # zero_copy_out: Detect writes a slot's detections straight into the slot's PINNED host buffer (its rows are written once,
+        # coalesced, never read back: layers/functions/detection.py `out=`), so there is no device-to-host copy, no copy-out stream and
+        # no event chain behind it -- a D2H that waits for step k's end in a stream of its own blocks whatever shares its hardware
+        # queue, the next H2D included (scripts/dev/stream_timeline.py).  result(slot) then waits for the step's own event.
+        self.zero_copy_out = bool(zero_copy_out)
+        # copy_in="own": batch k + 2's frames go to the device on the stream of the pipeline that will run them, right behind step k of
+        # that pipeline (AHEAD is a multiple of the pipeline count) -- no copy-in stream, no events between it and the steps; the
+        # pipeline pauses for the copy (0.35 ms at batch 32) while the other pipeline keeps the chip busy
+        if copy_in not in ("stream", "own") or (copy_in == "own" and AHEAD % NP):
+            raise ValueError("copy_in must be 'stream' or 'own' (own: the pipeline count has to divide %d)" % AHEAD)
+        self.copy_in = copy_in
+
         def make_step(eng, det):
-            def one_step(u8):
+            def one_step(u8, out=None):
                 # the frame stays uint8 until the first conv's loader reads it: resize to uint8 planes, a quarter of the
                 # fp32 tensor; the mean is subtracted inside the net (tdrn_net_io.reserved[3])
                 x = base_transform_u8(u8, size, mean)
                 r = eng.forward(x)
-                return det.forward(r["odm_loc"], r["conf"], priors, arm_loc_data=r["arm_loc"], scale=scale)
+                return det.forward(r["odm_loc"], r["conf"], priors, arm_loc_data=r["arm_loc"], scale=scale, out=out)
             return one_step
         steps = [make_step(e, d) for e, d in zip(engines, detects)]
         self._fn = steps[0]
@@ -97,7 +109,7 @@ class FrameStream(object):
             # one private pool per PIPELINE: a pipeline's steps run one after another on its stream, so their intermediates may
             # share memory (each slot's OUTPUT stays live and is never aliased); steps of different pipelines run concurrently
             with torch.cuda.graph(g, pool=self.graphs[s % NP].pool() if s >= NP else None):
-                out = steps[s % NP](self.dev_in[s])
+                out = steps[s % NP](self.dev_in[s], out=self.host_out[s] if self.zero_copy_out else None)
             self.graphs.append(g)
             self.dev_out.append(out)
         if not self.graph:
@@ -191,7 +203,19 @@ class FrameStream(object):
         """the slot the producer has to fill before the next run(): the batch AHEAD of the one that run() will launch"""
         return (self._k + AHEAD) % self.slots
 
+    def _pipe_stream(self, p):
+        if self._pipe_streams is not None:
+            return self._pipe_streams[p]
+        return torch.cuda.current_stream(self.dev) if p == 0 else self._extra_streams[p - 1]
+
     def _copy_in(self, slot):
+        if self.copy_in == "own":
+            cur = self._pipe_stream(slot % self.pipelines)
+            with torch.cuda.stream(cur):
+                cur.wait_event(self.ev_out[slot])        # (stream order covers the step that last read the buffer)
+                self.dev_in[slot].copy_(self.host_in[slot], non_blocking=True)
+                self.ev_in[slot].record(cur)
+            return
         with torch.cuda.stream(self._in_stream):
             self._in_stream.wait_event(self.ev_step[slot])      # the step that last read this device buffer has run
             self._in_stream.wait_event(self.ev_out[slot])       # ... and its detections have left the slot's output buffer, so
@@ -213,24 +237,29 @@ class FrameStream(object):
         """Queue: the copy-in of the batch in pinned_in(next_in()), the step of the oldest batch not yet run, the copy-out of
         its detections.  Returns that step's slot; never blocks the host."""
         s = self._k % self.slots
-        self._copy_in((self._k + AHEAD) % self.slots)
+        if self.copy_in != "own":
+            self._copy_in((self._k + AHEAD) % self.slots)
         p = s % self.pipelines
-        if self._pipe_streams is not None:
-            cur = self._pipe_streams[p]
-        else:
-            cur = torch.cuda.current_stream(self.dev) if p == 0 else self._extra_streams[p - 1]
+        cur = self._pipe_stream(p)
         with torch.cuda.stream(cur):
             cur.wait_event(self.ev_in[s])
             if self.graph:
                 self.graphs[s].replay()
+            elif self.zero_copy_out:
+                self._steps[p](self.dev_in[s], out=self.host_out[s])
             else:
                 cur.wait_event(self.ev_out[s])           # (the slot's previous detections have left its output buffer)
                 self.dev_out[s].copy_(self._steps[p](self.dev_in[s]))
             self.ev_step[s].record(cur)
-        with torch.cuda.stream(self._out_stream):
-            self._out_stream.wait_event(self.ev_step[s])
-            self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
-            self.ev_out[s].record(self._out_stream)
+            if self.zero_copy_out:
+                self.ev_out[s].record(cur)               # (the detections are on the host when the step is done)
+        if not self.zero_copy_out:
+            with torch.cuda.stream(self._out_stream):
+                self._out_stream.wait_event(self.ev_step[s])
+                self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
+                self.ev_out[s].record(self._out_stream)
+        if self.copy_in == "own":
+            self._copy_in((self._k + AHEAD) % self.slots)     # behind this step, on this pipeline's stream
         self._step_of[s] = self._k
         self._k += 1
         return Ticket(s, self._k - 1)

@@ -1008,8 +1008,33 @@ def test_two_steps_in_flight_equal_one_at_a_time():
     assert (want[0][..., 0] > 0).any()
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_frame_stream_with_two_pipelines_equals_unstreamed(graph):
+def test_detect_writes_into_a_given_buffer_device_or_pinned_host():
+    """Detect(...).forward(..., out=): the rows land in the caller's buffer -- on the device, or in pinned host memory (the streamed mode's
+    zero-copy hand-back) -- and are the rows the plain call returns; wrong shapes / pageable memory are refused."""
+    rng = np.random.RandomState(5)
+    B, P, Cn = 3, 6375, 21
+    pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
+    loc = torch.from_numpy(rng.randn(B, P, 4).astype(np.float32) * 0.2).to(DEV)
+    arm = torch.from_numpy(rng.randn(B, P, 4).astype(np.float32) * 0.2).to(DEV)
+    conf = torch.softmax(torch.from_numpy(rng.randn(B * P, Cn).astype(np.float32) * 3), dim=1).to(DEV)
+    det = Detect(Cn, 0, 200, 0.01, 0.45)
+    want = det.forward(loc, conf, pri, arm_loc_data=arm).clone()
+    assert (want[..., 0] > 0).any()
+    on_dev = torch.full((B, Cn, 200, 5), -1.0, device=DEV)
+    assert det.forward(loc, conf, pri, arm_loc_data=arm, out=on_dev) is on_dev and torch.equal(on_dev, want)
+    pinned = torch.full((B, Cn, 200, 5), -1.0).pin_memory()
+    assert det.forward(loc, conf, pri, arm_loc_data=arm, out=pinned) is pinned
+    torch.cuda.synchronize()
+    assert torch.equal(pinned, want.cpu())
+    with pytest.raises(ValueError):
+        det.forward(loc, conf, pri, arm_loc_data=arm, out=torch.empty((B, Cn, 200, 5)))              # pageable host memory
+    with pytest.raises(ValueError):
+        det.forward(loc, conf, pri, arm_loc_data=arm, out=torch.empty((B, Cn, 100, 5), device=DEV))
+
+
+@pytest.mark.parametrize("graph,zero_copy,copy_in", [(True, False, "stream"), (False, False, "stream"), (False, True, "stream"), (True, True, "stream"),
+                                                     (False, False, "own"), (True, False, "own")])
+def test_frame_stream_with_two_pipelines_equals_unstreamed(graph, zero_copy, copy_in):
     """FrameStream given two engines (slot s on pipeline s % 2): same results as the unstreamed step, slot after slot -- as one hipGraph
     per slot, and with the steps launched eagerly on pipeline streams picked by calibration (the streamed twin of InFlight.pick_streams)."""
     from tdrn_amd.stream import FrameStream
@@ -1018,7 +1043,7 @@ def test_frame_stream_with_two_pipelines_equals_unstreamed(graph):
     eng = net.engine(DEV)
     pri = PriorBox(mb_cfg["VOC_320"]).forward().to(DEV)
     B, slots, n = 4, 4, 11
-    fs = FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots, calibrate=not graph, graph=graph)
+    fs = FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots, calibrate=not graph, graph=graph, zero_copy_out=zero_copy, copy_in=copy_in)
     assert fs.pipelines == 2
     if not graph:
         assert fs.pipeline_calibration["picked"] in fs.pipeline_calibration["ms_per_step"] and fs.calibration is not None
