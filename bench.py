@@ -381,7 +381,7 @@ def main_other(args):
         trn_side, trn_ev = torch.cuda.Stream(dev), torch.cuda.Event()
         KEEP_ALIVE.append((trn_side, trn_ev))
 
-        def one_step(clips, batched=batched):
+        def one_step(clips, batched=batched, stat=stat, temp=temp, det=det, trn_side=trn_side, trn_ev=trn_ev):
             # evaluate_trn.py:438-467 over B clips at once: key frame -> static net (anchors + loc maps) -> temporal net (offsets
             # from the key frame's loc maps, reused by the frames up to the next key frame); Detect on the static anchors.
             if batched and args.trn_overlap:
@@ -431,6 +431,24 @@ def main_other(args):
 
     NF = 1
     launch_mode, launch_cal = ("hipGraph replay" if args.graph else "eager"), None
+    trn_flight = None
+    if trn and args.graph and batched and args.trn_overlap and args.in_flight > 1 and args.launch == "auto" and NB % 2 == 0:
+        # config 5 with two steps in flight: a second pipeline = twins of the static and the temporal model (own engines over the same
+        # weight blobs, own Detect, side stream and event), the two launched eagerly on calibrated streams; timed against the
+        # one-step-at-a-time hipGraph replays below and used if faster (as the headline configuration does)
+        from tdrn_amd.engine import InFlight
+        stat2, temp2 = stat.pipeline_twin(dev), temp.pipeline_twin(dev)
+        det2 = [Detect(NCLS, 0, 200, 0.01, 0.45) for _ in range(FPC)]
+        side2, ev2 = torch.cuda.Stream(dev), torch.cuda.Event()
+        KEEP_ALIVE.append((stat2, temp2, det2, side2, ev2))
+        step2 = lambda clips: one_step(clips, stat=stat2, temp=temp2, det=det2, trn_side=side2, trn_ev=ev2)
+
+        def make_trn_flight():
+            fl_ = InFlight(None, eng_t, xb, graph=False, steps=[lambda clips: one_step(clips), step2],
+                           engines=[eng_s, eng_t, stat2.engine(dev), temp2.engine(dev)])
+            KEEP_ALIVE.append(fl_)
+            return fl_
+        trn_flight = make_trn_flight
     if args.graph and not trn and args.in_flight > 1:
         # config 4: two steps in flight, as the headline configuration (tdrn_amd.engine.InFlight)
         from tdrn_amd.engine import InFlight
@@ -459,6 +477,13 @@ def main_other(args):
         graphs = [GraphedCall(one_step, xb[j]) for j in range(NB)]
         KEEP_ALIVE.append(graphs)
         step = lambda k: graphs[k % NB](graphs[k % NB].inputs[0])
+        if trn_flight is not None:
+            class _Replays(object):                      # (the one-step-at-a-time replays behind InFlight's launch(k))
+                launch = staticmethod(step)
+            chosen, launch_mode, launch_cal = _choose_launch(_Replays, trn_flight, args.steps, world * frames_per_step, tdist, torch, dev)
+            if launch_mode == "eager":
+                NF, step = 2, chosen.launch
+                engines = [(eng_s, 1), (eng_t, 1)]
     else:
         step = lambda k: one_step(xb[k % NB])
     for k in range(args.warmup):
@@ -470,8 +495,9 @@ def main_other(args):
     fps = world * frames_per_step * args.steps / dt
     one_at_a_time = None
     if NF > 1:
-        engines = engines[:1]                       # (the accounting passes below run engine 0 alone)
-        g1 = [GraphedCall(one_step, xb[j]) for j in range(NB)]
+        if not trn:
+            engines = engines[:1]                   # (the accounting passes below run engine 0 alone)
+        g1 = graphs if trn else [GraphedCall(one_step, xb[j]) for j in range(NB)]
         KEEP_ALIVE.append(g1)
         st1 = lambda k: g1[k % NB](g1[k % NB].inputs[0])
         for k in range(3):

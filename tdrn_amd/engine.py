@@ -337,12 +337,14 @@ class InFlight(object):
         fl.output(j)            # captured output of batch j (valid after fl.sync() or an event wait on fl.stream_of(j))
     """
 
-    def __init__(self, make_step, engine, batches, n=2, graph=True):
+    def __init__(self, make_step, engine, batches, n=2, graph=True, steps=None, engines=None):
+        # (steps / engines: pipelines built by the caller -- one step callable per pipeline and the engines to check() -- for steps that
+        # are more than one engine's forward, e.g. the TRN clips' static + temporal nets: bench.py --config 5)
         dev = engine.device
-        self.n = max(1, int(n))
-        self.engines = [engine] + [engine.clone() for _ in range(self.n - 1)]
+        self.n = max(1, int(n)) if steps is None else len(steps)
+        self.engines = ([engine] + [engine.clone() for _ in range(self.n - 1)]) if steps is None else list(engines or [engine])
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.n)]
-        self.steps = [make_step(e) for e in self.engines]
+        self.steps = [make_step(e) for e in self.engines] if steps is None else list(steps)
         self.batches = list(batches)
         self.graph = bool(graph)
         self.calls = []

@@ -78,6 +78,16 @@ class EngineModule(nn.Module):
             object.__setattr__(self, "_size_engines", {})        # they share the blob that was just replaced
         return self._engine
 
+    def pipeline_twin(self, device):
+        """A second handle on this model for a second step in flight (tdrn_amd.engine.InFlight): the same parameters and the same
+        packed weight blob, its own engine (workspace, lanes, offset-reuse state): `NetEngine.clone()` behind the module interface."""
+        import copy
+        twin = copy.copy(self)
+        object.__setattr__(twin, "_engine", self.engine(device).clone())
+        object.__setattr__(twin, "_size_engines", {})
+        object.__setattr__(twin, "_dirty", False)
+        return twin
+
     def engine_for(self, x):
         """The engine that runs input x.  The reference nets are fully convolutional: multi_eval.py:526-547
         feeds one net frames of 192..704 (1216) pixels.  The plan of a tdrn_net is static per input size, so

@@ -954,6 +954,59 @@ def test_trn_static_net_beside_the_temporal_trunk():
         assert all(torch.equal(u, v) for u, v in zip(got, w))
 
 
+def test_trn_two_clip_steps_in_flight_equal_one_at_a_time():
+    """bench.py --config 5 with two steps in flight: the second pipeline is a `pipeline_twin()` of the static and of the temporal model
+    (own engines -- workspace, lanes, offset state -- over the same weight blobs), its own side stream and event; the two pipelines are
+    launched eagerly (InFlight(steps=...)), their streams picked by calibration.  Every step's outputs are the serial order's, bit for
+    bit, turn after turn."""
+    from tdrn_amd.engine import InFlight
+    stat, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, False), seed=0)
+    stat.set_plan_flags(_lib.PLAN_ONE_STREAM)
+    temp, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, True), seed=1)
+    for n in (stat, temp):
+        n.set_compute_dtype("bf16")
+    Bk, F, NB = 2, 3, 4
+    batches = [torch.from_numpy(synth.synth_frames(F * Bk, 320, seed=71 + k)).to(DEV).view(F, Bk, 3, 320, 320) for k in range(NB)]
+
+    def serial(frames):
+        s_loc, _, maps = stat(frames[0], ret_loc=True)
+        loc, conf = temp(frames.view(F * Bk, 3, 320, 320), ref_loc=maps)[:2]
+        return loc, conf, s_loc
+    want = [[t.clone() for t in serial(b)] for b in batches]
+    torch.cuda.synchronize()
+
+    def make(st, tp):
+        side, ev = torch.cuda.Stream(DEV), torch.cuda.Event()
+
+        def overlapped(frames):
+            main = torch.cuda.current_stream(DEV)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                s_loc, _, maps = st(frames[0], ret_loc=True)
+                ev.record(side)
+            loc, conf = tp(frames.view(F * Bk, 3, 320, 320), ref_loc=maps, ref_event=ev)[:2]
+            main.wait_stream(side)
+            for t_ in [s_loc] + list(maps):
+                t_.record_stream(main)
+            return loc, conf, s_loc
+        return overlapped
+    stat2, temp2 = stat.pipeline_twin(DEV), temp.pipeline_twin(DEV)
+    assert stat2.engine(DEV) is not stat.engine(DEV) and stat2.engine(DEV).weights.data_ptr() == stat.engine(DEV).weights.data_ptr()
+    fl = InFlight(None, temp.engine(DEV), batches, graph=False, steps=[make(stat, temp), make(stat2, temp2)],
+                  engines=[stat.engine(DEV), temp.engine(DEV), stat2.engine(DEV), temp2.engine(DEV)])
+    assert fl.n == 2
+    for phase in range(2):
+        for turn in range(3):
+            for k in range(NB):
+                fl.launch(turn * NB + k)
+            fl.sync()
+            for j in range(NB):
+                assert all(torch.equal(u, v) for u, v in zip(fl.output(j), want[j])), (phase, turn, j)
+        if phase == 0:
+            assert fl.pick_streams(candidates=3, steps=NB)["picked"]
+    fl.check()
+
+
 def test_two_steps_in_flight_equal_one_at_a_time():
     """Round 5, the default schedule of bench.py / FrameStream: two whole steps in flight (tdrn_amd.engine.InFlight -- pipeline p =
     its own engine handle, workspace, stream and hipGraph over ONE weight blob).  Every batch's detections are, bit for bit, what
