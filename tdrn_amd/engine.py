@@ -325,6 +325,11 @@ def _clone_tree(o):
 class InFlight(object):
     """N whole steps in flight (round 5; the default schedule of bench.py and FrameStream is N = 2).
 
+    graph=True: one hipGraph replay per step on the pipeline's stream.  graph=False: the step's launches are issued eagerly on it -- on
+    ROCm 7.2 two replays on two streams hardly overlap (step k + 1 starts when step k ends: scripts/dev/inflight_timeline.py) while eager
+    pipelines do; call pick_streams() once to put the pipelines' main lanes on hardware queues that do not serialise them (+8 % frames/s
+    over the replays at batch 32; bench.py --launch auto times both and runs the faster).
+
     A step -- forward + Detect of one batch -- is a ~2-ms trunk of convolutions that fill the chip, followed by ~1 ms in which ~40
     small dependent launches, the deformable heads and Detect leave most CUs idle.  With two pipelines (each its own engine handle,
     workspace, HIP stream and hipGraph; ONE packed weight blob) the tail of step k runs under the trunk of step k + 1:

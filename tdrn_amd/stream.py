@@ -18,6 +18,11 @@ step's own stream (a 2.7-MB device-to-pinned copy there is a blit kernel that qu
 0.85 of resident -- that alone was the whole shortfall of the first versions); the H2D as a node of the step's graph (the
 executor ran it ~2.4 ms into the step, in series with Detect: 0.86-0.91); copying only one batch ahead (the copy then has
 to start and finish inside one step).
+Round 5, options: graph=False launches the slots' steps eagerly (two hipGraph replays on two streams do not overlap on ROCm 7.2; eager
+pipelines do) on pipeline streams picked by a calibration of their own (_pick_pipeline_streams); zero_copy_out=True lets Detect write
+into the slot's pinned host buffer (no D2H, no copy-out stream); copy_in="own" issues batch k + 2's H2D on the stream of the pipeline that
+will run it (no copy-in stream).  Measured with two eager pipelines: 10.3-10.9k frames/s (0.86-0.90 of the resident 11.9-12.3k),
+copy_in="own" +3 %, zero-copy out -5 %: profiles/r05_experiments.md.
 Protocol: batches 0 and 1 go into pinned_in(0), pinned_in(1), then prime(); before every run() -- which launches the
 oldest batch not yet run -- the producer writes the batch TWO ahead of it into pinned_in(next_in()); result(slot) is
 that run's output.  run() returns the slot as a TICKET (an int that also carries the step number): a consumer that lags
