@@ -72,6 +72,26 @@ for k in range(100):
 fl.sync()
 dt = (time.perf_counter() - t0) / 100
 print("shift %s/%s NP %d NB %d %s queues %s flags %s grid %s: %.3f ms per step = %.0f frames/s" % (os.environ.get("SHIFT_A", "0"), os.environ.get("SHIFT_B", "0"), NP, NB, os.environ.get("MODE", "graph"), os.environ.get("GPU_MAX_HW_QUEUES", "4"), os.environ.get("FLAGS", "0"), os.environ.get("TDRN_MAIN_GRID", "-"), dt * 1e3, B / dt))
+if os.environ.get("OPS", "0") != "0" and not fl.graph:
+    # per-launch hipEvents on the production lanes of BOTH pipelines while they overlap: where does a step wait?
+    eng.set_profile(1)
+    eng.forward(xb[0]); eng.forward(xb[0])
+    torch.cuda.synchronize()
+    alone = {o["name"]: o["ms"] for o in eng.op_stats()}
+    for e in fl.engines:
+        e.set_profile(2)
+    for k in range(3 * NB):
+        fl.launch(k)
+    fl.sync()
+    tl = fl.engines[0].op_timeline()
+    for e in fl.engines:
+        e.set_profile(0)
+    prev_end = {}
+    print("%-42s lane %9s %9s %8s %8s %8s" % ("launch (pipeline 0, other pipeline running)", "start", "end", "us", "alone", "gap"))
+    for o in tl:
+        gap = (o["start"] - prev_end.get(o["lane"], o["start"])) * 1e3
+        print("%-42s %4d %9.3f %9.3f %8.1f %8.1f %8.1f" % (o["name"], o["lane"], o["start"], o["end"], o["ms"] * 1e3, alone.get(o["name"], 0) * 1e3, gap))
+        prev_end[o["lane"]] = o["end"]
 if SHOW <= 0:
     sys.exit(0)
 E = lambda: torch.cuda.Event(enable_timing=True)
