@@ -765,8 +765,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the box / score error and detection-agreement blocks (oracle forwards on the host)")
     ap.add_argument("--no-modes", action="store_true", help="skip timing the other precisions")
     ap.add_argument("--streams", type=int, default=1, help="split each step's batch over this many concurrent HIP streams")
-    ap.add_argument("--launch", choices=["auto", "fixed"], default="auto",
-                    help="headline configuration, two steps in flight: auto = time hipGraph replay AND eager launches briefly and run the timed region with the faster (reported in config.launch); fixed = what --graph says")
+    ap.add_argument("--launch", choices=["auto", "fixed", "eager"], default="auto",
+                    help="two steps in flight: auto = time hipGraph replays AND eager pipelines (streams picked by calibration) briefly and run the timed region with the faster (reported in config.launch); "
+                         "eager = the eager pipelines without asking; fixed = what --graph says (replays, or one eager step at a time)")
     ap.add_argument("--graph", type=int, default=1, help="1: the step (forward + Detect) is one captured hipGraph replay; 0: eager launches")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="whole steps in flight (tdrn_amd.engine.InFlight): resident batch j runs on pipeline j %% N (own engine handle, workspace, "
@@ -875,7 +876,7 @@ def main():
     # The default schedule (round 5): TWO steps in flight.  Step k replays resident batch k % NB on pipeline (k % NB) % NF; the timed
     # region is still K steps between two device-wide synchronisations.  `roofline` below comes from single-pipeline profiling
     # passes of engine 0 (a launch's duration with another step's kernels beside it says nothing about the kernel).
-    NF = max(1, args.in_flight) if ((args.graph or os.environ.get("TDRN_BENCH_EAGER_IN_FLIGHT")) and NS == 1) else 1
+    NF = max(1, args.in_flight) if ((args.graph or args.launch == "eager" or os.environ.get("TDRN_BENCH_EAGER_IN_FLIGHT")) and NS == 1) else 1
     while NB % NF:
         NF -= 1
 
@@ -910,8 +911,13 @@ def main():
 
     launch_mode, launch_cal = ("hipGraph replay" if (args.graph and NS == 1) else "eager"), None
     if NF > 1:
-        flight = in_flight_stepper(eng, bool(args.graph))
-        if args.graph and args.launch == "auto":
+        flight = in_flight_stepper(eng, bool(args.graph) and args.launch != "eager")
+        if args.launch == "eager":
+            for k in range(4):
+                flight.launch(k)
+            flight.pick_streams()
+            launch_mode = "eager"
+        elif args.graph and args.launch == "auto":
             flight, launch_mode, launch_cal = _choose_launch(flight, lambda: in_flight_stepper(eng, False), args.steps, world * B, tdist, torch, dev)
         elif not args.graph:
             launch_mode = "eager"
