@@ -612,7 +612,7 @@ def main_other(args):
         NSL = 3
         while NSL % NF:
             NSL += 1
-        fs = FrameStream([eng] + [eng.clone() for _ in range(NF - 1)] if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL, graph=launch_mode != "eager")
+        fs = FrameStream([eng] + [eng.clone() for _ in range(NF - 1)] if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL, graph=launch_mode != "eager", copy_in="own" if launch_mode == "eager" and NF == 2 else "stream")
         rng = np.random.RandomState(7)
         for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -638,7 +638,7 @@ def main_other(args):
         stream_blk = {"frames_per_s": round(world * B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
                       "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
                       "copy_streams_picked": (fs.calibration or {}).get("picked"), "pipeline_streams_picked": (fs.pipeline_calibration or {}).get("picked"),
-                      "launch": "hipGraph replay" if fs.graph else "eager",
+                      "launch": "hipGraph replay" if fs.graph else "eager", "copies": "on the pipelines' own streams" if fs.copy_in == "own" else "copy-in / copy-out streams",
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
                       "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): per slot (one hipGraph, or the same launches issued eagerly: `launch`) tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL)}
@@ -1002,7 +1002,7 @@ def main():
         while NSL % NF:
             NSL += 1
         fs_engines = [eng] + [eng.clone() for _ in range(NF - 1)]                     # NF steps in flight here too (slot s on pipeline s % NF)
-        fs = FrameStream(fs_engines if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL, graph=launch_mode != "eager")     # one pinned batch per slot: the slots' batches cycle; launched the way the headline chose
+        fs = FrameStream(fs_engines if NF > 1 else eng, Detect(NCLS, 0, 200, 0.01, 0.45), pri, B, slots=NSL, graph=launch_mode != "eager", copy_in="own" if launch_mode == "eager" and NF == 2 else "stream")     # one pinned batch per slot: the slots' batches cycle; launched the way the headline chose
         rng = np.random.RandomState(7)
         for sl in range(NSL):
             fs.pinned_in(sl).copy_(torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)))
@@ -1028,7 +1028,7 @@ def main():
         stream_blk = {"frames_per_s": round(world * B * args.steps / ts, 2), "ms_per_step": round(ts / args.steps * 1e3, 4),
                       "vs_resident": round((world * B * args.steps / ts) / fps, 4), "repetitions": len(t_stream),
                       "copy_streams_picked": (fs.calibration or {}).get("picked"), "pipeline_streams_picked": (fs.pipeline_calibration or {}).get("picked"),
-                      "launch": "hipGraph replay" if fs.graph else "eager",
+                      "launch": "hipGraph replay" if fs.graph else "eager", "copies": "on the pipelines' own streams" if fs.copy_in == "own" else "copy-in / copy-out streams",
                       "detections_identical_to_unstreamed": bool(torch.equal(got, want)),
                       "per_step": "copy-in stream: H2D %.1f MB of uint8 BGR 500x375 frames (pinned), two batches ahead | compute streams (slot s on pipeline s mod in-flight): per slot (one hipGraph, or the same launches issued eagerly: `launch`) tdrn_preprocess_u8 (resize, frames stay uint8), net (mean subtracted in the first conv's loader), Detect | copy-out stream: D2H %.1f MB of detections; %d slots, event-chained"
                                   % (B * 375 * 500 * 3 / 1e6, got.numel() * 4 / 1e6, NSL),

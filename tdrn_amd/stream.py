@@ -21,8 +21,9 @@ to start and finish inside one step).
 Round 5, options: graph=False launches the slots' steps eagerly (two hipGraph replays on two streams do not overlap on ROCm 7.2; eager
 pipelines do) on pipeline streams picked by a calibration of their own (_pick_pipeline_streams); zero_copy_out=True lets Detect write
 into the slot's pinned host buffer (no D2H, no copy-out stream); copy_in="own" issues batch k + 2's H2D on the stream of the pipeline that
-will run it (no copy-in stream).  Measured with two eager pipelines: 10.3-10.9k frames/s (0.86-0.90 of the resident 11.9-12.3k),
-copy_in="own" +3 %, zero-copy out -5 %: profiles/r05_experiments.md.
+will run it, and the detections' D2H behind that pipeline's step (no copy stream at all; the pipeline pauses ~0.4 ms per step for its
+copies while the other one keeps the chip busy).  Measured with two eager pipelines: copy streams 10.3-11.0k frames/s, copy_in="own"
+10.9-11.3k (0.89 of the resident 12.45k on that box), zero-copy out -5 %: profiles/r05_experiments.md.
 Protocol: batches 0 and 1 go into pinned_in(0), pinned_in(1), then prime(); before every run() -- which launches the
 oldest batch not yet run -- the producer writes the batch TWO ahead of it into pinned_in(next_in()); result(slot) is
 that run's output.  run() returns the slot as a TICKET (an int that also carries the step number): a consumer that lags
@@ -259,10 +260,15 @@ class FrameStream(object):
             if self.zero_copy_out:
                 self.ev_out[s].record(cur)               # (the detections are on the host when the step is done)
         if not self.zero_copy_out:
-            with torch.cuda.stream(self._out_stream):
-                self._out_stream.wait_event(self.ev_step[s])
-                self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
-                self.ev_out[s].record(self._out_stream)
+            if self.copy_in == "own":                    # ... and the detections leave on the pipeline's stream too: no copy stream at all
+                with torch.cuda.stream(cur):
+                    self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
+                    self.ev_out[s].record(cur)
+            else:
+                with torch.cuda.stream(self._out_stream):
+                    self._out_stream.wait_event(self.ev_step[s])
+                    self.host_out[s].copy_(self.dev_out[s], non_blocking=True)
+                    self.ev_out[s].record(self._out_stream)
         if self.copy_in == "own":
             self._copy_in((self._k + AHEAD) % self.slots)     # behind this step, on this pipeline's stream
         self._step_of[s] = self._k
