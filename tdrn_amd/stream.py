@@ -135,7 +135,8 @@ class FrameStream(object):
         if calibrate:
             if not self.graph and NP == 2:
                 self._pick_pipeline_streams()
-            self._pick_streams()
+            if self.copy_in != "own":                    # (own: there are no copy streams to place)
+                self._pick_streams()
 
     def _pick_pipeline_streams(self, candidates=4, steps=6):
         """Eager mode, two pipelines: which hardware queues the two main lanes sit on decides how much of a step overlaps the next

@@ -1099,7 +1099,8 @@ def test_frame_stream_with_two_pipelines_equals_unstreamed(graph, zero_copy, cop
     fs = FrameStream([eng, eng.clone()], Detect(21, 0, 200, 0.01, 0.45), pri, B, slots=slots, calibrate=not graph, graph=graph, zero_copy_out=zero_copy, copy_in=copy_in)
     assert fs.pipelines == 2
     if not graph:
-        assert fs.pipeline_calibration["picked"] in fs.pipeline_calibration["ms_per_step"] and fs.calibration is not None
+        assert fs.pipeline_calibration["picked"] in fs.pipeline_calibration["ms_per_step"]
+        assert (fs.calibration is None) == (copy_in == "own")          # (own: no copy streams to place)
     rng = np.random.RandomState(12)
     feeds = [torch.from_numpy(rng.randint(0, 256, size=(B, 375, 500, 3), dtype=np.uint8)) for _ in range(n)]
     fs.prime(feeds[:2])
