@@ -810,6 +810,8 @@ def main():
 
     net = build_net("test", args.size, NCLS, 1024, 1, True, True)
     net.set_compute_dtype(args.dtype)
+    if os.environ.get("TDRN_BENCH_PLAN_FLAGS"):          # (A/B runs of a kernel choice: tdrn_hip.h TDRN_PLAN_*)
+        net.set_plan_flags(int(os.environ["TDRN_BENCH_PLAN_FLAGS"]))
     if rank == 0:
         sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})

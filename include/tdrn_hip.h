@@ -243,6 +243,8 @@ typedef struct {
 #define TDRN_PLAN_NO_CONV_WS    8192 /* the Cin = 64 layers (conv1_2, conv2_1) stay on conv3x3_patch.hip instead of the weight-stationary conv3x3_ws.hip */
 #define TDRN_PLAN_NO_YGEMM_V2  16384 /* transform-then-sample heads: the transform on the round-3 schedule of ygemm_k256 (two barriers per tile, stores behind the
                                        multiply phase) instead of the round-5 one (deform.hip ygemm_k256_v2_kernel); same bits                    */
+#define TDRN_PLAN_NO_HEAD3X3   32768 /* the narrow fp32 3x3 heads (ARM loc) stay on conv_igemm.hip instead of head3x3.hip (different K order: the fp32 sums
+                                       differ in their last bits)                                                                        */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 

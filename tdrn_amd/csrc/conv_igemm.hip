@@ -557,6 +557,7 @@ int conv_splitk_choice(const ConvArgs &a)
     const int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
     const long long blocks = (long long)cdiv(a.B * a.Ho * a.Wo, 128) * (a.Npad / bn) * a.phases;
     if (conv_patch_enabled() && patch_conv_supported(a) && a.H * a.W >= conv_patch_enabled() * 400) return 1;
+    if (head3x3_supported(a)) return 1;                  // (head3x3.hip takes the launch whole)
     if (blocks >= 160 || nk < 8) return 1;
     int s = (int)((384 + blocks - 1) / blocks);
     if (s > nk / 4) s = nk / 4;
@@ -622,6 +623,7 @@ int launch_conv(const ConvArgs &a, hipStream_t s)
     if (p.splits == 1 && use_patch && patch_conv_supported(a) && a.H * a.W >= use_patch * 400)
         return launch_conv3x3_patch(a, nullptr, s);
     if (a.fuse_x) return TDRN_E_UNSUPPORTED;             // only the patch kernel computes the first conv itself
+    if (p.splits == 1 && head3x3_supported(a)) return launch_head3x3(a, s);      // the narrow fp32 heads (ARM loc)
     if (p.splits == 1 && pw1x1_supported(a)) {           // wide pointwise layers: dwpw.hip's persistent GEMM (same bits)
         const int rc1 = launch_pw1x1(a, s);
         if (rc1 != TDRN_E_UNSUPPORTED) return rc1;       // (it declines launches too small to fill the chip)

@@ -65,6 +65,9 @@ size_t conv_chain_ctr_bytes();
 int launch_conv_chain(const ChainLayer *layers, int n, unsigned *ctr, hipStream_t s, unsigned *status = nullptr);
 int conv_splitk_choice(const ConvArgs &a);          // 1 = no split
 size_t conv_splitk_bytes(const ConvArgs &a, int splits);
+// narrow 3x3/s1/p1 heads with fp32 output (<= 16 columns: the ARM loc heads), head3x3.hip; kdisable bit 8 (TDRN_PLAN_NO_HEAD3X3) declines
+int head3x3_supported(const ConvArgs &a);
+int launch_head3x3(const ConvArgs &a, hipStream_t s);
 // warp-specialised 3x3/s1/p1 kernel (conv3x3_patch.hip); out_pool = optional fused MaxPool2d(2,2) output
 int conv_patch_enabled();                       // TDRN_CONV_PATCH (default 1)
 int patch_conv_supported(const ConvArgs &a);   // 0 = no, 32/16 = 2-D tiles, -1 = flat tiles

@@ -681,7 +681,8 @@ struct tdrn_net {
         kdisable = ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PP) ? 1 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PP_SK) ? 2 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_YGEMM_V2) ? 128 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_YGEMM_V2) ? 128 : 0) |
+                   ((cfg.plan_flags & TDRN_PLAN_NO_HEAD3X3) ? 256 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)

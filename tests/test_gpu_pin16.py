@@ -433,6 +433,23 @@ def test_kernel_choice_never_changes_a_bit(dtype):
             other._engine.check()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_arm_loc_heads_on_head3x3_equal_conv_igemm_up_to_fp32_summation_order(dtype):
+    """head3x3.hip (round 5) runs the 12-column fp32 ARM loc heads with the source map staged once per channel chunk instead of once per
+    tap; its K order is (chunk, tap, channel) where conv_igemm.hip's is (tap, chunk, channel), so the two agree to fp32 summation
+    noise, not bit for bit: the default plan against TDRN_PLAN_NO_HEAD3X3, arm_loc of a VGG and of a MobileNet net, three batches
+    (ragged last tiles: 1600 / 400 / 100 / 25 pixels per image).  The exact-input stage checks above bound both against fp64."""
+    for model, args in (VGG, ("dualrefinedet_mobilenet", (320, 21, 1, True))):
+        for batch, seed in ((1, 61), (5, 62), (32, 63)):
+            base, _ = _build(model, args, dtype=dtype)
+            other, _ = _build(model, args, dtype=dtype, flags=_lib.PLAN_NO_HEAD3X3)
+            x = torch.from_numpy(synth.synth_frames(batch, args[0], seed=seed)).to(DEV)
+            a, b = base(x)[0], other(x)[0]                      # arm_loc (B, P, 4)
+            assert a.shape == b.shape and torch.isfinite(a).all()
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-6 * max(scale, 1.0) + 1e-6, (model, batch, float((a - b).abs().max()), scale)
+
+
 def test_lost_handoff_is_an_error_not_a_hang():
     """Fault injection (TDRN_PLAN_FAULT_HANDOFF): the producers of conv3x3_pp's chained split never raise their flag.  The
     consumers' bounded polls run out; the launch ENDS (no hang), the status word is raised, tdrn_net_check reports
