@@ -468,8 +468,10 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
         if (i < mp.n && blk >= mp.block_start[i]) prob = i;
     const SampleParams &p = mp.p[prob];
     constexpr int MAXR = 34 * 4;                        // corner rows of one output pixel (9 + 25 taps)
-    __shared__ unsigned s_off[4][MAXR + 8];             // per wave: byte offset of a corner's Y row (incl. the tap's columns)
-    __shared__ float s_w[4][MAXR + 8];                  // ... and its bilinear weight (0: tap rejected)
+    // per wave and corner row: {byte offset of the row in Y (incl. the tap's columns), bilinear weight (0: tap rejected)} -- one 8-byte LDS
+    // read per row (round 5; two arrays before), padded with weight-0 copies of the last row up to whole batches of 36 rows, so that the
+    // gather loop below is branch-free
+    __shared__ uint2 s_ow[4][MAXR + 8];
     __shared__ float s_red[4][6][kSampleCols];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = (blk - mp.block_start[prob]) * 4 + wave;                 // one wave = one output pixel (stride 1: Ho = H)
@@ -507,10 +509,12 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
         const unsigned colb = p.tap_major ? (unsigned)(B.col0 + tl) * (unsigned)p.M * (unsigned)(kSampleCols * 2) : (unsigned)(deform_y_col(B.col0 + tl) * 2);
         const unsigned rowb = p.tap_major ? (unsigned)(kSampleCols * 2) : (unsigned)(p.ycs * 2);
         const unsigned img = (unsigned)(b * HW);
-        s_off[wave][4 * lane + 0] = (img + q1) * rowb + colb; s_w[wave][4 * lane + 0] = w1;
-        s_off[wave][4 * lane + 1] = (img + q2) * rowb + colb; s_w[wave][4 * lane + 1] = w2;
-        s_off[wave][4 * lane + 2] = (img + q3) * rowb + colb; s_w[wave][4 * lane + 2] = w3;
-        s_off[wave][4 * lane + 3] = (img + q4) * rowb + colb; s_w[wave][4 * lane + 3] = w4;
+        s_ow[wave][4 * lane + 0] = make_uint2((img + q1) * rowb + colb, __float_as_uint(w1));
+        s_ow[wave][4 * lane + 1] = make_uint2((img + q2) * rowb + colb, __float_as_uint(w2));
+        s_ow[wave][4 * lane + 2] = make_uint2((img + q3) * rowb + colb, __float_as_uint(w3));
+        s_ow[wave][4 * lane + 3] = make_uint2((img + q4) * rowb + colb, __float_as_uint(w4));
+        if (lane == p.n_taps - 1)                       // rows past the end re-read the last row with weight 0 (as the loop did before)
+            for (int r = nrows; r < 36 * ((nrows + 35) / 36); ++r) s_ow[wave][r] = make_uint2((img + q4) * rowb + colb, 0u);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -518,17 +522,18 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const SampleMulti mp
     const int j = lane / 10, c = lane - 10 * j;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (lane < 60) {
-        // branch-free batches of six independent 16-byte loads (rows past the end re-read the last row with weight 0)
+        // branch-free batches of six independent 16-byte loads (the table is padded to whole batches); Y's base in scalar registers,
+        // 32-bit offsets (Y < 4 GiB: ygemm_fill)
         const int nb = (nrows + 35) / 36;
+        const __attribute__((address_space(1))) char *yb = (const __attribute__((address_space(1))) char *)p.y;
         for (int ib = 0; ib < nb; ++ib) {
             u32x4 raw[6];
             float wgt[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int r = 6 * (6 * ib + u) + j;
-                const int rc = r < nrows ? r : nrows - 1;
-                wgt[u] = r < nrows ? s_w[wave][rc] : 0.f;
-                raw[u] = *(const u32x4 *)(p.y + s_off[wave][rc] + c * 16);
+                const uint2 ow = s_ow[wave][6 * (6 * ib + u) + j];
+                wgt[u] = __uint_as_float(ow.y);
+                raw[u] = *(const __attribute__((address_space(1))) u32x4 *)(yb + (ow.x + (unsigned)(c * 16)));
             }
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
