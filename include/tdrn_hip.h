@@ -245,6 +245,8 @@ typedef struct {
                                        multiply phase) instead of the round-5 one (deform.hip ygemm_k256_v2_kernel); same bits                    */
 #define TDRN_PLAN_NO_HEAD3X3   32768 /* the narrow fp32 3x3 heads (ARM loc) stay on conv_igemm.hip instead of head3x3.hip (different K order: the fp32 sums
                                        differ in their last bits)                                                                        */
+#define TDRN_PLAN_TS_ONE_RANGE  65536 /* transform-then-sample heads: the whole batch as ONE range (Y of the whole batch in its buffer) instead of ranges
+                                       whose Y fits the memory-side cache (192 MiB); same bits -- for tools and tests that read Y back       */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 

@@ -682,7 +682,7 @@ struct tdrn_net {
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_YGEMM_V2) ? 128 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_HEAD3X3) ? 256 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_HEAD3X3) ? 256 : 0) | ((cfg.plan_flags & TDRN_PLAN_TS_ONE_RANGE) ? 512 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
@@ -1470,6 +1470,21 @@ struct tdrn_net {
                             Bc = fit < Bc ? fit : Bc;
                         }
                         if (Bc < 1) { rc = TDRN_E_UNSUPPORTED; break; }
+                        {   // ... and (round 5) a range's Y is kept below 192 MiB, so that it is still in the 256-MiB memory-side cache when
+                            // the sampling launch gathers it: the pair of launches 277-285 -> 254-255 us alone at batch 32 (two ranges of
+                            // 16 frames; ranges of 8 / 4 frames lose it again to the extra launches), 520 -> 488 us at MobileNet's batch 64.
+                            // Per-frame arithmetic untouched.  TDRN_TS_RANGE_MB=0 switches it off, another value is another bound.
+                            static long long cap_mb = -1;
+                            if (cap_mb < 0) { const char *e = getenv("TDRN_TS_RANGE_MB"); cap_mb = e ? atoll(e) : 192; }
+                            size_t per_frame = 0;
+                            for (int i = 0; i < n_dargs; ++i)
+                                per_frame += (size_t)dargs[i].H * dargs[i].W * ops[ts_op[i]].y_cols * es;       // (one column group's Y: a group's two launches are adjacent)
+                            if (cap_mb > 0 && per_frame > 0 && !(kdisable & 512)) {
+                                long long fit = (long long)((size_t)cap_mb << 20) / (long long)per_frame;
+                                fit = fit < 1 ? 1 : fit;
+                                if (fit < Bc) Bc = (int)fit;
+                            }
+                        }
                         // output columns in groups of 80 (deform.hip: a Y row is 80 columns): group g = columns [80 g, 80 g + 80) of
                         // [12 loc ; 3 * classes conf], its own weight rows, Y region, transform and sampling launch
                         const int n_groups = ops[ts_op[0]].y_groups;

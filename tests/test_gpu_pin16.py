@@ -45,6 +45,8 @@ def _build(modname, args, phase="test", seed=0, flags=0, dtype="bf16"):
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
+    if phase == "train":
+        flags |= _lib.PLAN_TS_ONE_RANGE      # (the stage checks read the whole batch's Y back: not in cache-sized ranges of frames)
     if flags:
         net.set_plan_flags(flags)
     net.set_compute_dtype(dtype)
@@ -424,7 +426,8 @@ def test_kernel_choice_never_changes_a_bit(dtype):
         # from a materialised conv1_1 -- against conv3x3_patch.hip's loader / consumer kernel on the same layers)
         for flags in (_lib.PLAN_NO_CONV_PP, _lib.PLAN_NO_PP_SK, _lib.PLAN_NO_CONV_PP | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_CONV_WS,
                       _lib.PLAN_NO_CONV_WS | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_FUSE_FIRST,
-                      _lib.PLAN_NO_YGEMM_V2):        # (+ the transform of the deformable heads on its round-3 schedule)
+                      _lib.PLAN_NO_YGEMM_V2,         # (+ the transform of the deformable heads on its round-3 schedule)
+                      _lib.PLAN_TS_ONE_RANGE):       # (+ the heads over the whole batch at once instead of cache-sized ranges of frames)
             other, _ = _build(VGG[0], args, dtype=dtype, flags=flags)
             got = _outputs(other, x)
             assert len(got) == len(want)
