@@ -360,7 +360,7 @@ def main_other(args):
             net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         net.eval()
         t0 = time.perf_counter()
-        eng = net.adopt_broadcast_weights(src=0, device=dev) if world > 1 else net.engine(dev)
+        eng = net.adopt_broadcast_weights(src=0, device=dev) if tdist.active() else net.engine(dev)
         torch.cuda.synchronize()
         return net, sd, eng, (time.perf_counter() - t0) * 1e3
 
@@ -661,7 +661,8 @@ def main_other(args):
         "repetitions": {"n": len(reps), "reported": "median", "timed_steps_total": len(reps) * args.steps, "ms_per_step_min": round(reps[0] / args.steps * 1e3, 4), "ms_per_step_max": round(reps[-1] / args.steps * 1e3, 4)},
         "fps_per_gpu": round(fps / world, 2), "forward_only_ms_per_step": round(fwd_ms, 4), "forward_tflops": round(gflop_step / fwd_ms, 2),
         "build": build, "roofline": roofline, "kernels": kernels,
-        "n_ranks_seen": world if world == 1 else int(torch.distributed.get_world_size()), "weights_broadcast_ms": round(bcast_ms, 2) if world > 1 else None,
+        "n_ranks_seen": int(torch.distributed.get_world_size()) if tdist.active() else world, "weights_broadcast_ms": round(bcast_ms, 2) if tdist.active() else None,
+        "dist_backend": torch.distributed.get_backend() if tdist.active() else None,
         "numa_pin": tdist.verify_pin(NUMA_PIN, local_rank),
     }
     if one_at_a_time is not None:
@@ -817,7 +818,7 @@ def main():
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
     t_bc = time.perf_counter()
-    if world > 1:
+    if tdist.active():                                           # (N > 1, or TDRN_DIST_FORCE_GROUP=1: the RCCL path at world size 1)
         eng = net.adopt_broadcast_weights(src=0, device=dev)     # the one collective: weights over xGMI
     else:
         eng = net.engine(dev)
@@ -1097,8 +1098,9 @@ def main():
             "kernels": kernels,
             # N > 1: what the first hardware run should tell -- how many ranks really joined, what the one collective cost, where
             # each rank's feeder threads were pinned (tdrn_amd/dist.py pin_to_gpu_numa_node; rank 0's record)
-            "n_ranks_seen": world if world == 1 else int(torch.distributed.get_world_size()),
-            "weights_broadcast_ms": round(bcast_ms, 2) if world > 1 else None,
+            "n_ranks_seen": int(torch.distributed.get_world_size()) if tdist.active() else world,
+            "weights_broadcast_ms": round(bcast_ms, 2) if tdist.active() else None,
+            "dist_backend": torch.distributed.get_backend() if tdist.active() else None,
             "numa_pin": tdist.verify_pin(NUMA_PIN, local_rank),
         }
         if one_at_a_time is not None:

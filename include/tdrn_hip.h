@@ -240,13 +240,15 @@ typedef struct {
 #define TDRN_PLAN_NO_PW1X1      1024 /* the wide 1x1 convs stay on conv_igemm.hip instead of dwpw.hip's persistent GEMM (pw1x1_kernel)     */
 #define TDRN_PLAN_NO_DW_SLIDE   2048 /* depthwise 3x3 layers on the one-row strip kernel instead of the sliding-window one (same bits)       */
 #define TDRN_PLAN_DW_SLIDE_ALL  4096 /* ... the sliding-window kernel (8-row segments) at every batch, also where it leaves CUs idle       */
-#define TDRN_PLAN_NO_CONV_WS    8192 /* the Cin = 64 layers (conv1_2, conv2_1) stay on conv3x3_patch.hip instead of the weight-stationary conv3x3_ws.hip */
+#define TDRN_PLAN_NO_CONV_WS    8192 /* the pooled Cin = 64 layer (conv1_2, with the first conv fused) stays on conv3x3_patch.hip instead of the weight-stationary conv3x3_ws.hip (conv2_1, full-resolution output, is on conv3x3_patch.hip either way unless TDRN_CONV_WS=2) */
 #define TDRN_PLAN_NO_YGEMM_V2  16384 /* transform-then-sample heads: the transform on the round-3 schedule of ygemm_k256 (two barriers per tile, stores behind the
                                        multiply phase) instead of the round-5 one (deform.hip ygemm_k256_v2_kernel); same bits                    */
 #define TDRN_PLAN_NO_HEAD3X3   32768 /* the narrow fp32 3x3 heads (ARM loc) stay on conv_igemm.hip instead of head3x3.hip (different K order: the fp32 sums
                                        differ in their last bits)                                                                        */
 #define TDRN_PLAN_TS_ONE_RANGE  65536 /* transform-then-sample heads: the whole batch as ONE range (Y of the whole batch in its buffer) instead of ranges
                                        whose Y fits the memory-side cache (192 MiB); same bits -- for tools and tests that read Y back       */
+#define TDRN_PLAN_NO_PATCH_TAIL 131072 /* conv3x3_patch.hip runs whole 128-cout items only: no 64-cout half items in an XCD's last, at most half-filled
+                                        * round (the tail split of round 6: same MFMA rows, same K order -- bit-identical; for A/B runs and the test) */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */
 

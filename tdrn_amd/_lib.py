@@ -30,6 +30,7 @@ class NetConfig(C.Structure):
 PLAN_NO_FUSE_FIRST, PLAN_NO_LATE_SIDE, PLAN_ONE_STREAM, PLAN_NO_DEFORM_TS, PLAN_CHAIN = 1, 2, 4, 8, 16      # tdrn_hip.h TDRN_PLAN_*
 PLAN_NO_CONV_PP, PLAN_NO_PP_SK, PLAN_NO_CONV_PATCH, PLAN_FAULT_HANDOFF, PLAN_DWPW, PLAN_NO_PW1X1 = 32, 64, 128, 256, 512, 1024
 PLAN_NO_DW_SLIDE, PLAN_DW_SLIDE_ALL, PLAN_NO_CONV_WS, PLAN_NO_YGEMM_V2, PLAN_NO_HEAD3X3, PLAN_TS_ONE_RANGE = 2048, 4096, 8192, 16384, 32768, 65536
+PLAN_NO_PATCH_TAIL = 131072
 E_DEVICE = -8
 
 

@@ -28,6 +28,7 @@
 // tap falls outside the image.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -55,6 +56,7 @@ struct PatchParams {
     int m_tiles, n_tiles, items;   // items = m_tiles * n_tiles
     int M;                         // B*H*W
     int max_wgs;                   // > 0: cap on the persistent grid
+    int tail_split;                // 16-bit 128-cout kernels: an XCD's last, at most half-filled round of items runs as 64-cout half items
     // FUSE instantiation only: the layer's input is the first conv's output (3 -> 64 channels, 3x3, pad 1, stride 1, BN folded,
     // ReLU), computed here from the raw frames instead of being read back from HBM
     const float *fx, *fw, *fb;     // frames NCHW fp32 [B][3][S][S]; first-conv weights [64][27] (k = c*9 + r*3 + q) and bias [64], fp32
@@ -192,9 +194,38 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     const int per_xcd = (p.items + 7) >> 3, istride = ((int)gridDim.x + 7) >> 3;
     int avail = p.items - xcd * per_xcd;
     avail = avail < per_xcd ? avail : per_xcd;
-    const int n_it = avail > slot ? (avail - slot + istride - 1) / istride : 0;
+    int n_full = avail > slot ? (avail - slot + istride - 1) / istride : 0;
     const int item0 = xcd * per_xcd + slot;
+    // ---- tail split (round 6).  1600 items on 256 workgroups are 6.25 rounds: after six rounds an XCD has 8 items left for its 32
+    // workgroups and the launch ends with 24 of every 32 CUs idle for a whole item (per-workgroup stamps, profiles/r05_experiments.md:
+    // 7-13 % of the chip time of conv2_1 / 2_2 / 3_1 / 3_3).  When an XCD's last round is at most HALF filled, its items are cut in two
+    // along the couts -- 2 * rem HALF ITEMS of 256 pixels x 64 couts, one per workgroup -- and a half item runs on the same eight
+    // consumer waves with one 32-cout accumulator tile each (the BN = 64 kernel's wave tile).  Every output element still sees the
+    // same MFMA instruction with the same operand rows in the same K order: bit-identical whatever the batch (= the item count) does
+    // to the cut (tests/test_gpu_pin16.py, TDRN_PATCH_TAIL=0 keeps whole items).  A half item costs ~0.6 of a whole one (half the MFMAs,
+    // the same patch loads and barriers), so the last round shrinks from 1 to ~0.6 item times.
+    [[maybe_unused]] int n_tail = 0, tail_enc = 0;       // tail_enc = 2 * item + cout half (one scalar: the kernel is at its SGPR budget)
+    constexpr bool TAILOK = BN == 128 && sizeof(DT) == 2 && !FUSE;
+    if constexpr (TAILOK) {
+        if (p.tail_split && avail > 0) {
+            const int full = avail / istride, rem = avail - full * istride;
+            if (full > 0 && rem > 0 && 2 * rem <= istride) {
+                n_full = full;
+                if (slot < 2 * rem) {
+                    n_tail = 1;
+                    tail_enc = 2 * (xcd * per_xcd + full * istride) + slot;
+                }
+            }
+        }
+    }
+    const int n_it = n_full + n_tail;
     const int n_steps = n_it * nchunks * 9;
+    // item `it` of this workgroup: pixel tile, first cout, whole (BN couts) or half (64 couts) item
+    auto item_mt = [&](int it) { return (it < n_full ? item0 + it * istride : tail_enc >> 1) / p.n_tiles; };
+    auto item_c0 = [&](int it) {
+        const int item = it < n_full ? item0 + it * istride : tail_enc >> 1;
+        return (item % p.n_tiles) * BN + (it < n_full ? 0 : (tail_enc & 1) * 64);
+    };
     const int RS = TW ? TW + 2 : p.W;                  // patch row stride of one image row
 
     if (wave >= 8) {
@@ -330,8 +361,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
         };
         int table_mt = -1;
-        auto patch_table = [&](int item) {              // per pixel tile: where my patch rows live
-            const int mt = item / p.n_tiles;
+        auto patch_table = [&](int mt) {                // per pixel tile: where my patch rows live
             if (mt == table_mt) return;
             table_mt = mt;
             const long long rowbytes = (long long)p.Cin * ES;
@@ -366,13 +396,19 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         int ws = 0, w_it = 0, w_cc = 0, w_tap = 0, wslot = 0;
         const char *wbase = p.w;
         unsigned wk = 0;
-        auto weight_item = [&]() { wbase = p.w + (size_t)((item0 + w_it * istride) % p.n_tiles) * BN * p.Ktot * ES; };
+        int w_pieces = WL;                              // weight pieces per step of the item being streamed (half items: WL / 2)
+        auto weight_item = [&]() {
+            wbase = p.w + (size_t)item_c0(w_it) * p.Ktot * ES;
+            if constexpr (TAILOK) w_pieces = w_it < n_full ? WL : WL / 2;
+        };
         constexpr bool wfixed = (TDRN_PATCH_ABLATE & 16) != 0, pfixed = (TDRN_PATCH_ABLATE & 32) != 0;
-        auto load_weights = [&]() {                     // issue step ws into ring slot wslot, then advance
+        auto load_weights = [&]() -> int {              // issue step ws into ring slot wslot, then advance; returns the pieces issued
+            const int np = w_pieces;
             if (live) {
                 char *dst = smem + OFF_W + wslot * WBYTES;
 #pragma unroll
-                for (int k = 0; k < WL; ++k) glds(wfixed ? p.w + (woff[k] & 0xffffu) : wbase + wk + woff[k], dst + (lw + 4 * k) * 1024);
+                for (int k = 0; k < WL; ++k)
+                    if (!TAILOK || k < np) glds(wfixed ? p.w + (woff[k] & 0xffffu) : wbase + wk + woff[k], dst + (lw + 4 * k) * 1024);
             }
             ++ws;
             wslot = wslot == RING - 1 ? 0 : wslot + 1;
@@ -386,6 +422,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 }
                 wk = (unsigned)(w_cc * 128);
             }
+            return np;
         };
         auto load_patch = [&](int j, unsigned ccoff, char *dstbuf) {
             if (!live || lw + 4 * j >= kPatchSlots || FUSE) return;
@@ -417,7 +454,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         if (n_it > 0) {
             weight_item();
             if constexpr (!FUSE) {
-                patch_table(item0);
+                patch_table(item_mt(0));
 #pragma unroll
                 for (int j = 0; j < kSlotsPerLoader; ++j) load_patch(j, 0u, smem);
             }
@@ -426,7 +463,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 if (k < n_steps) load_weights();
             next_patch_chunk();
             if (lw == 0 && live)
-                glds(lane < BN / 4 ? (const char *)(p.bias + (item0 % p.n_tiles) * BN) + lane * 16 : p.zero, smem + OFF_B);
+                glds(lane < (n_full > 0 ? BN : 64) / 4 ? (const char *)(p.bias + item_c0(0)) + lane * 16 : p.zero, smem + OFF_B);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -439,10 +476,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             // NEXT chunk's patch (taps 0-4: two pieces, tap 5: one); then make sure everything issued
             // before this step has landed, and release the step.
             int issued = 0;
-            if (ws < n_steps) {
-                load_weights();
-                issued = WL;
-            }
+            if (ws < n_steps) issued = load_weights();
             if constexpr (FUSE) {
                 // tap 0: the raw tile of the NEXT item (its patch is computed behind this item's last barrier, below)
                 if (tap == 0 && c_it + 1 < n_it) issued += load_raw(item0 + (c_it + 1) * istride, (c_it + 1) & 1);
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
                 const unsigned ccoff = (unsigned)(p_cc * 128);
                 switch (tap) {
                     case 0:
-                        patch_table(item0 + p_it * istride);
+                        patch_table(item_mt(p_it));
                         load_patch(0, ccoff, dstbuf); load_patch(1, ccoff, dstbuf); issued += 2; break;
                     case 1: load_patch(2, ccoff, dstbuf); load_patch(3, ccoff, dstbuf); issued += 2; break;
                     case 2: load_patch(4, ccoff, dstbuf); load_patch(5, ccoff, dstbuf); issued += 2; break;
@@ -463,8 +497,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             if (lw == 0 && c_cc == nchunks - 1 && tap == 6 && c_it + 1 < n_it) {
                 // the NEXT item's bias -> the other LDS bias slot (the consumers initialise their
                 // accumulators from it when that item starts; this item reads slot c_it & 1)
-                const int nt = (item0 + (c_it + 1) * istride) % p.n_tiles;
-                if (live) glds(lane < BN / 4 ? (const char *)(p.bias + nt * BN) + lane * 16 : p.zero, smem + OFF_B);
+                if (live) glds(lane < (c_it + 1 < n_full ? BN : 64) / 4 ? (const char *)(p.bias + item_c0(c_it + 1)) + lane * 16 : p.zero, smem + OFF_B);
                 issued += 1;
             }
             // ring of 3: everything issued before this step has landed; ring of 4: before the previous step
@@ -528,9 +561,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     long long tile_pix0 = 0;                            // 2-D: global pixel of the tile's (0,0); flat: mt*256
     int tile_row0 = 0, tile_x0 = 0;                     // 2-D: b*H + y and x of the tile's (0,0)
     auto setup_item = [&](int it) {
-        const int item = item0 + it * istride;
-        const int mt = item / p.n_tiles;
-        n0 = (item - mt * p.n_tiles) * BN;
+        const int mt = item_mt(it);
+        n0 = item_c0(it);
         if (mt == cur_mt) return;
         cur_mt = mt;
         if (TW) {
@@ -580,10 +612,11 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         if constexpr (sizeof(DT) == 2) return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, pack2<DT>(a, b)), relu_lo));
         else return 0u;
     };
-    auto epilogue16 = [&]() {
+    auto epilogue16 = [&](auto wcn_tag) {
         if constexpr (sizeof(DT) == 2) {
-            const int cbase = n0 + chalf * BNH;                 // first cout of my span
-            constexpr int NPAIR = 2 * WC;                       // chunk pairs per pixel (2 or 4)
+            constexpr int WCN = decltype(wcn_tag)::value;       // accumulator tiles per wave along the couts: WC, or 1 in a half item
+            const int cbase = n0 + chalf * (32 * WCN);          // first cout of my span
+            constexpr int NPAIR = 2 * WCN;                      // chunk pairs per pixel (2 or 4)
             if (p.out && !(TDRN_PATCH_ABLATE & 4)) {
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
@@ -611,9 +644,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     if (TW == 32 && pt == 1) break;
-                    uint2 pk[WC][4];
+                    uint2 pk[WCN][4];
 #pragma unroll
-                    for (int ci = 0; ci < WC; ++ci)
+                    for (int ci = 0; ci < WCN; ++ci)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             float m[4];
@@ -668,8 +701,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     };
 
     // ---- epilogue of one item, fp32 (wave-private staging strip -> whole-line stores) -------------------
-    auto epilogue = [&]() {
-        if constexpr (sizeof(DT) == 2) { epilogue16(); return; }
+    auto epilogue = [&](auto wcn_tag) {
+        if constexpr (sizeof(DT) == 2) { epilogue16(wcn_tag); return; }
         const int my_c = n0 + chalf * BNH + my_ch * P16;
         auto pixel_of = [&](int i) -> long long {       // global pixel of tile-local pixel i (or -1)
             if (TW) return tile_pix0 + (long long)(i >> LGTW) * p.W + (i & (TW - 1));
@@ -777,16 +810,18 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     const char *psb = smem;
     int prow[2] = {base_i[0], base_i[1]};
     int psw[2] = {(base_i[0] >> 1) & 7, (base_i[1] >> 1) & 7};
-    auto load_frags = [&](u32x4 *wf, u32x4 *pf, int kk) {
+    auto load_frags = [&](auto wcn_tag, u32x4 *wf, u32x4 *pf, int kk) {
+        constexpr int WCN = decltype(wcn_tag)::value;
         if (!compute) return;
         const int lc = 2 * kk + hh;
 #pragma unroll
-        for (int ci = 0; ci < WC; ++ci) wf[ci] = *(const u32x4 *)(wsb + (chalf * BNH + ci * 32 + r32) * 128 + ((lc ^ wsw) << 4));
+        for (int ci = 0; ci < WCN; ++ci) wf[ci] = *(const u32x4 *)(wsb + (chalf * (32 * WCN) + ci * 32 + r32) * 128 + ((lc ^ wsw) << 4));
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) pf[pt] = *(const u32x4 *)(psb + prow[pt] * 128 + ((lc ^ psw[pt]) << 4));
     };
     // m0/m1: all-ones, or zero for lanes whose tap falls outside the image (flat tiles only; branch-free)
-    auto mma_frags = [&](const u32x4 *wf, u32x4 *pf, unsigned m0, unsigned m1) {
+    auto mma_frags = [&](auto wcn_tag, const u32x4 *wf, u32x4 *pf, unsigned m0, unsigned m1) {
+        constexpr int WCN = decltype(wcn_tag)::value;
         if (!compute) return;
         if constexpr (FLAT) {
 #pragma unroll
@@ -796,19 +831,19 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
             }
         }
 #pragma unroll
-        for (int ci = 0; ci < WC; ++ci)
+        for (int ci = 0; ci < WCN; ++ci)
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) MmaP<DT>::run(wf[ci], pf[pt], acc[ci][pt]);
     };
     // accumulators start at the bias (staged into LDS by loader wave 0 one item ahead)
-    auto init_acc = [&](int it_) {
+    auto init_acc = [&](auto wcn_tag) {
+        constexpr int WCN = decltype(wcn_tag)::value;
         const char *bsrc = smem + OFF_B;
-        (void)it_;
 #pragma unroll
-        for (int ci = 0; ci < WC; ++ci)
+        for (int ci = 0; ci < WCN; ++ci)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *(const f32x4 *)(bsrc + (chalf * BNH + ci * 32 + 8 * g + 4 * hh) * 4);
+                const f32x4 bv = *(const f32x4 *)(bsrc + (chalf * (32 * WCN) + ci * 32 + 8 * g + 4 * hh) * 4);
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -820,39 +855,41 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
     __builtin_amdgcn_s_barrier();                       // prologue operands landed
     if (TDRN_PATCH_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // static: the younger half
     if (TDRN_PATCH_PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // static: all consumers over the loaders
+    typedef std::integral_constant<int, WC> full_t;      // a whole item: WC accumulator tiles per wave along the couts
+    typedef std::integral_constant<int, 1> half_t;       // a half item of the tail split: one
     if (n_it > 0) {
         setup_item(0);
-        init_acc(0);
-        load_frags(wfA, pfA, 0);
+        init_acc(full_t{});
+        load_frags(full_t{}, wfA, pfA, 0);
     }
     int it = 0, cc = 0, tap = 0, tq = 0, delta = 0, wslot = 0, pbuf = 0;
     STAMP_DECL
-#pragma unroll 1
-    for (int g = 0; g < n_steps; ++g) {
+    // one (chunk, tap) step of the current item; `wcn` says how many accumulator tiles the item has per wave
+    auto step = [&](auto wcn) {
         unsigned m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
         if constexpr (FLAT) {
             m0 = ((tapmask[0] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
             m1 = ((tapmask[1] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
         }
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(1);
-        load_frags(wfB, pfB, 1);
+        load_frags(wcn, wfB, pfB, 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frags(wfA, pfA, m0, m1);
+        mma_frags(wcn, wfA, pfA, m0, m1);
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(wfA, pfA, 2);
+        load_frags(wcn, wfA, pfA, 2);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frags(wfB, pfB, m0, m1);
+        mma_frags(wcn, wfB, pfB, m0, m1);
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(wfB, pfB, 3);
+        load_frags(wcn, wfB, pfB, 3);
         __builtin_amdgcn_sched_barrier(0);
-        mma_frags(wfA, pfA, m0, m1);
+        mma_frags(wcn, wfA, pfA, m0, m1);
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(0);
         // every LDS read of this step has returned -> the step's buffers may be refilled after the barrier
         __builtin_amdgcn_s_waitcnt(0xC07F);
         STAMP(0);                                           // K slices 0-2: reads + 12 MFMAs + drain
         __builtin_amdgcn_s_barrier();
         STAMP(1);                                           // barrier (waiting for the loaders / the other consumers)
-        // ---- advance to step g+1 and start its first reads, THEN finish this step's last K-slice ----
+        // ---- advance to the next step and start its first reads, THEN finish this step's last K-slice ----
         // (measured and rejected: the cursor and the read addresses computed before the barrier, in the shadow of slice 2's
         // MFMAs, so that only the four reads stand between the barrier and slice 3: -7 % on the family)
         const bool item_done = tap == 8 && cc == nchunks - 1;
@@ -876,25 +913,39 @@ __global__ __launch_bounds__(768) void conv3x3_patch_kernel(const PatchParams p)
         }
         // (FUSE: behind an item's last barrier the single patch buffer is being rewritten: its first reads wait for the
         // extra barrier after the epilogue)
-        if (!(FUSE && item_done)) load_frags(wfA, pfA, 0);     // (past the last step this reads stale but in-bounds LDS; unused)
+        if (!(FUSE && item_done)) load_frags(wcn, wfA, pfA, 0);    // (past the last step this reads stale but in-bounds LDS; unused)
         __builtin_amdgcn_sched_barrier(0);
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(1);
-        mma_frags(wfB, pfB, m0, m1);
+        mma_frags(wcn, wfB, pfB, m0, m1);
         if (TDRN_PATCH_PRIO == 0) __builtin_amdgcn_s_setprio(0);
         STAMP(2);                                           // K slice 3 under the next step's first reads
         if (item_done) {
-            epilogue();
+            epilogue(wcn);
             ++it;
             if (it < n_it) {
                 setup_item(it);
-                init_acc(it);
+                if (TAILOK && it >= n_full) {
+                    // the next item is this workgroup's half item: its bias is 64 floats, its weight rows sit at 32 * chalf of the
+                    // slot, and the first fragments fetched above used a whole item's rows: fetch them again
+                    init_acc(half_t{});
+                    load_frags(half_t{}, wfA, pfA, 0);
+                } else {
+                    init_acc(full_t{});
+                }
                 if constexpr (FUSE) {
                     __builtin_amdgcn_s_barrier();           // the loaders have written the next item's patch
-                    load_frags(wfA, pfA, 0);
+                    load_frags(wcn, wfA, pfA, 0);
                 }
             }
             STAMP(3);                                       // epilogue + next item's set-up
         }
+    };
+    const int n_steps_full = n_full * nchunks * 9;
+#pragma unroll 1
+    for (int g = 0; g < n_steps_full; ++g) step(full_t{});
+    if constexpr (TAILOK) {
+#pragma unroll 1
+        for (int g = n_steps_full; g < n_steps; ++g) step(half_t{});
     }
     STAMP_FLUSH;
 #ifdef TDRN_PATCH_WGTIME
@@ -1017,6 +1068,9 @@ int launch_conv3x3_patch(const ConvArgs &a, void *out_pool, hipStream_t s)
     p.ablate = ablate;
     p.fx = a.fuse_x; p.fw = a.fuse_w; p.fb = a.fuse_b; p.fS = a.H; p.fCout = a.fuse_cout;
     p.max_wgs = a.max_wgs > 0 ? (a.max_wgs / 8) * 8 : 0;
+    static int tail = -1;
+    if (tail < 0) { const char *e = getenv("TDRN_PATCH_TAIL"); tail = e ? atoi(e) : 1; }
+    p.tail_split = tail && !(a.kdisable & 1024);     // (TDRN_PLAN_NO_PATCH_TAIL)
     if (p.items <= 0) return TDRN_OK;
 #ifdef TDRN_PATCH_STAMP
     // diagnostics build: synchronise after every launch and print the mean cycles per wave in each state

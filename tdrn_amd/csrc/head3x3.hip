@@ -28,6 +28,7 @@ struct Head3Params {
     float *out;                    // element (b, y, x, co) at out + b * o_bs + y * o_rs + x * o_cs + co
     long long o_bs, o_rs, o_cs;
     int B, H, W, Cin, Cout, relu, tiles_per_img;
+    int vec16;                     // out is 16-byte aligned: a pixel's four columns go out as one dwordx4
 };
 
 constexpr int kH3MaxW = 64;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void head3x3_kernel(const Head3Params p)
         f32x4 v = acc[nb];
         if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         const int left = p.Cout - 4 * kg;
-        if (left >= 4) *(f32x4 *)dst = v;
+        if (left >= 4 && p.vec16) *(f32x4 *)dst = v;
         else
             for (int i = 0; i < left; ++i) dst[i] = v[i];
     }
@@ -169,9 +170,10 @@ int head3x3_supported(const ConvArgs &a)
     if (a.Cout < 1 || a.Cout > 16 || a.Npad < 16 || a.Cin % 64) return 0;
     if ((long long)a.H * a.W * a.Cin * 2 >= (1ll << 32)) return 0;                 // 32-bit byte offsets inside an image
     if ((long long)a.Npad * 9 * a.Cin * 2 >= (1ll << 32)) return 0;
-    // 16-byte stores: four consecutive columns of a pixel
+    // 16-byte stores: four consecutive columns of a pixel.  Geometry only -- the caller's POINTER alignment must not choose the
+    // kernel (head3x3 and conv_igemm differ in fp32 K order, and a frame's arithmetic depends on geometry alone): a base that is
+    // not 16-byte aligned (a sliced `out=` tensor) keeps this kernel and stores the four columns one by one (p.vec16 = 0).
     if ((a.o_base | a.o_bs | a.o_rs | a.o_cs) & 3) return 0;
-    if (((size_t)a.out) & 15) return 0;
     return 1;
 }
 
@@ -183,6 +185,7 @@ int launch_head3x3(const ConvArgs &a, hipStream_t s)
     p.in = (const char *)a.in; p.w = (const char *)a.w; p.bias = a.bias;
     p.out = (float *)a.out + a.o_base;
     p.o_bs = a.o_bs; p.o_rs = a.o_rs; p.o_cs = a.o_cs;
+    p.vec16 = (((size_t)p.out) & 15) == 0;
     p.B = a.B; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.relu = a.relu;
     p.tiles_per_img = (a.H * a.W + 255) / 256;
     const long long blocks = (long long)a.B * p.tiles_per_img;

@@ -82,7 +82,8 @@ int conv_pp_sk_enabled();                       // TDRN_CONV_PP_SK (default 1)
 size_t conv_pp_sk_bytes();
 // weight-stationary 3x3/s1/p1 kernel for the 16-bit Cin == 64 layers (conv3x3_ws.hip: the whole weight tile resident in LDS, the
 // activations in a ring of image rows, the first conv optionally computed by its producer waves); launch_conv3x3_patch hands those
-// layers over to it (TDRN_CONV_WS=0 / kdisable bit 6 keep the loader/consumer kernel).  Same output bits.
+// layers over to it when their output is POOLED -- by default that is conv1_2 alone; a full-resolution output (conv2_1) is declined
+// unless TDRN_CONV_WS=2 (it measured slower there) -- and TDRN_CONV_WS=0 / kdisable bit 6 keep the loader/consumer kernel.  Same output bits.
 int ws_conv_supported(const ConvArgs &a);
 int launch_conv3x3_ws(const ConvArgs &a, void *out_pool, hipStream_t s);
 void conv_ws_force(int v);                      // dev harness: -1 = environment, 0 / 1 = forced

@@ -222,7 +222,6 @@ struct tdrn_net {
     int first_conv(const std::string &w, bool bias, const std::string &bn, int Cout, int stride, int S)
     {
         const int So = (S + 2 - 3) / stride + 1;
-        x_t = T(3, S, S, true);
         Op o; o.kind = OP_FIRST; o.stat = ST_FIRST;
         o.Cin = 3; o.Cout = Cout; o.stride = stride; o.relu = 1; o.hw = S;
         o.w = w; o.bn = bn;
@@ -682,7 +681,8 @@ struct tdrn_net {
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_PATCH) ? 4 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_PW1X1) ? 8 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_DW_SLIDE) ? 16 : 0) | ((cfg.plan_flags & TDRN_PLAN_DW_SLIDE_ALL) ? 32 : 0) |
                    ((cfg.plan_flags & TDRN_PLAN_NO_CONV_WS) ? 64 : 0) | ((cfg.plan_flags & TDRN_PLAN_NO_YGEMM_V2) ? 128 : 0) |
-                   ((cfg.plan_flags & TDRN_PLAN_NO_HEAD3X3) ? 256 : 0) | ((cfg.plan_flags & TDRN_PLAN_TS_ONE_RANGE) ? 512 : 0);
+                   ((cfg.plan_flags & TDRN_PLAN_NO_HEAD3X3) ? 256 : 0) | ((cfg.plan_flags & TDRN_PLAN_TS_ONE_RANGE) ? 512 : 0) |
+                   ((cfg.plan_flags & TDRN_PLAN_NO_PATCH_TAIL) ? 1024 : 0);
         fault_handoff = (cfg.plan_flags & TDRN_PLAN_FAULT_HANDOFF) ? 1 : 0;
         // build_net() only constructs 320 / 512 nets, but they are fully convolutional and multi_eval.py runs them at
         // 192 ... 1216 (every tested size is a multiple of 64, so all four pyramid levels are exact)
@@ -701,6 +701,34 @@ struct tdrn_net {
         }
         if (rc != TDRN_OK) return rc;
         if (plan_error != TDRN_OK) return plan_error;
+        // The fp32 (3, S, S) copy of uint8 frames (plans whose first conv reads fp32: every one but the conv3x3_ws route) costs no
+        // workspace and no tensor index of a layer: it is appended LAST and ALIASED with the first layer output behind the second op
+        // that is large enough -- that tensor is dead while ops 0 / 1, the only readers of the copy, run (the engine's forwards are
+        // stream-ordered, a second step in flight has its own workspace).  Round-5 advisor finding: 1.2-3 MB per frame and engine
+        // clone were allocated in front of every other tensor for a fallback most callers never take.
+        if (!ops.empty() && ops[0].kind == OP_FIRST) {
+            const size_t need = align_up((size_t)3 * cfg.size * cfg.size * 4, 256);
+            auto touched_early = [&](int t) {
+                for (size_t i = 0; i < 2 && i < ops.size(); ++i)
+                    if (ops[i].in == t || ops[i].out == t || ops[i].res == t || ops[i].pool_t == t || ops[i].off_t == t) return true;
+                return false;
+            };
+            int victim = -1;
+            for (size_t i = 2; i < ops.size() && victim < 0; ++i)
+                for (int t : {ops[i].out, ops[i].pool_t}) {
+                    if (t < 0 || victim >= 0 || touched_early(t)) continue;
+                    const Tensor &v = tensors[t];
+                    if (align_up((size_t)v.Cpad * v.H * v.W * (v.f32 ? 4 : es), 256) >= need) victim = t;
+                }
+            if (victim >= 0) {
+                Tensor t;
+                t.C = 3; t.H = cfg.size; t.W = cfg.size; t.f32 = true; t.Cpad = 3; t.off = tensors[victim].off;
+                tensors.push_back(t);
+                x_t = (int)tensors.size() - 1;
+            } else {
+                x_t = T(3, cfg.size, cfg.size, true);
+            }
+        }
         // L2Norm of conv4_3 / conv5_3 right behind its producer and on a side lane: it is HBM-bound and needs no
         // LDS, so it runs under the next (LDS-filling) conv of the trunk, and the lateral TCB convs and ARM heads
         // that read it can start while conv5 / fc6 / fc7 -- which leave CUs idle -- are still running, instead of

@@ -13,11 +13,24 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def group_forced():
+    """TDRN_DIST_FORCE_GROUP=1: build the process group -- and run every collective of this module -- at world size 1 too.
+    That is how the RCCL branches below are executed on a 1-GPU box (tests/test_gpu_dist.py::test_rccl_*, `bench.py --gpus 1`
+    with the variable set): a one-rank communicator goes through the same ncclCommInitRank / ncclBroadcast / ncclAllGather /
+    ncclAllReduce entry points as an 8-rank one, only without a peer on the other end of xGMI."""
+    return os.environ.get("TDRN_DIST_FORCE_GROUP") == "1"
+
+
+def active():
+    """Whether this module's collectives run: a process group exists and has peers (or TDRN_DIST_FORCE_GROUP says so)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or group_forced())
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1).
-    backend: "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo"."""
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1 unless TDRN_DIST_FORCE_GROUP=1).
+    backend: "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".  Call before the first GPU call of the process."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or group_forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -147,7 +160,7 @@ def shard_stream(n, rank, world):
 
 def broadcast_blob(blob, src=0):
     """The one collective of the path: replicate the packed weight blob."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.broadcast(blob, src=src)
     return blob
 
@@ -158,7 +171,7 @@ def gather_results(local, rank, world, dst=0):
     hold different numbers of frames: the leading sizes are exchanged first and the payload padded to the largest -- on the
     tensor's own device with RCCL, through the host with gloo.  Anything else falls back to gather_object (control plane,
     pickled: fine for a few scalars, not for detections -- at 8 x 9k frames/s that would be 6 GB/s of pickling on rank 0)."""
-    if world == 1 or not dist.is_initialized():
+    if not active():
         return [local]
     nccl = dist.get_backend() == "nccl"
     ctl_dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
@@ -209,7 +222,7 @@ def gather_results(local, rank, world, dst=0):
 
 
 def max_over_ranks(value, device=None):
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -217,5 +230,5 @@ def max_over_ranks(value, device=None):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.barrier()

@@ -322,6 +322,18 @@ def _clone_tree(o):
     return o
 
 
+def _record_tree(o, stream):
+    if isinstance(o, torch.Tensor):
+        if o.is_cuda:
+            o.record_stream(stream)
+    elif isinstance(o, dict):
+        for v in o.values():
+            _record_tree(v, stream)
+    elif isinstance(o, (list, tuple)):
+        for v in o:
+            _record_tree(v, stream)
+
+
 class InFlight(object):
     """N whole steps in flight (round 5; the default schedule of bench.py and FrameStream is N = 2).
 
@@ -337,9 +349,18 @@ class InFlight(object):
     and 9 000 three-pipeline replays, profiles/r05_attribution/soak*.txt).  Resident batch j is captured on pipeline j % N, so
     n_batches should be a multiple of N.
 
-        fl = InFlight(lambda eng: (lambda x: detect(eng.forward(x)...)), engine, batches, n=2)
+        def make_step(eng):                     # called ONCE PER PIPELINE: everything a step writes besides the engine's own
+            detect = Detect(21, 0, cfg, ...)    # workspace must be created in here -- a Detect owns ONE device scratch (_ws), so a
+            return lambda x: detect(eng.forward(x), priors)   # Detect shared by two pipelines would be written by two steps at once
+        fl = InFlight(make_step, engine, batches, n=2)
         fl.launch(k)            # step k: replays batch k % len(batches) on its pipeline's stream; never blocks the host
-        fl.output(j)            # captured output of batch j (valid after fl.sync() or an event wait on fl.stream_of(j))
+        fl.output(j)            # output of batch j: valid after fl.sync()
+
+    Reading an output from ANOTHER stream without fl.sync(): graph=True outputs are static buffers, an event wait on fl.stream_of(j)
+    is enough.  graph=False outputs are fresh allocations of pipeline p's stream and the next launch of batch j returns the previous
+    ones to that stream's allocator pool -- a consumer stream that merely waited on an event could read recycled memory: ask for them
+    with fl.output(j, consumer=stream), which records the stream on every tensor of the output (torch keeps the blocks until that
+    stream's work behind the call has finished).
     """
 
     def __init__(self, make_step, engine, batches, n=2, graph=True, steps=None, engines=None):
@@ -415,8 +436,11 @@ class InFlight(object):
     def stream_of(self, j):
         return self.streams[j % self.n]
 
-    def output(self, j):
-        return self.calls[j].outputs if self.graph else self._eager_out[j]
+    def output(self, j, consumer=None):
+        out = self.calls[j].outputs if self.graph else self._eager_out[j]
+        if consumer is not None and not self.graph:
+            _record_tree(out, consumer)
+        return out
 
     def sync(self):
         torch.cuda.synchronize(self.dev)

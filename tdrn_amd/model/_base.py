@@ -17,6 +17,8 @@ class EngineModule(nn.Module):
         object.__setattr__(self, "_size_engines", {})
         object.__setattr__(self, "_engine_args", kwargs)
         object.__setattr__(self, "_dirty", True)
+        object.__setattr__(self, "_packs", 0)             # how often this module has (re)packed: what a pipeline_twin watches
+        object.__setattr__(self, "_twin_of", None)
         object.__setattr__(self, "compute_dtype", os.environ.get("TDRN_DTYPE", "fp32"))
 
     # precision switches select the MFMA input type instead of casting the fp32 master params
@@ -67,6 +69,8 @@ class EngineModule(nn.Module):
         object.__setattr__(self, "_dirty", True)
 
     def engine(self, device):
+        if self._twin_of is not None:
+            return self._twin_engine(device)
         if self._engine is None:
             args = dict(self._engine_args)
             args["dtype"] = self.compute_dtype
@@ -75,17 +79,36 @@ class EngineModule(nn.Module):
         if self._dirty or self._engine.device != torch.device(device):
             self._engine.load(super().state_dict(), device)
             object.__setattr__(self, "_dirty", False)
+            object.__setattr__(self, "_packs", self._packs + 1)
             object.__setattr__(self, "_size_engines", {})        # they share the blob that was just replaced
+        return self._engine
+
+    def _twin_engine(self, device):
+        """A twin never packs: it follows its source.  When the source has re-packed since the twin's engine was cloned
+        (load_state_dict, set_compute_dtype, set_plan_flags, .to(), repack() -- each leaves the source dirty or with a new
+        blob), the twin re-clones from the source's CURRENT engine, so both pipelines always run the same weights and plan."""
+        src = self._twin_of
+        main = src.engine(device)                        # (re-packs the source first if it is dirty)
+        if self._engine is None or self._twin_packs != src._packs or self._engine.weights is not main.weights:
+            object.__setattr__(self, "_engine", main.clone())
+            object.__setattr__(self, "_twin_packs", src._packs)
+            object.__setattr__(self, "_size_engines", {})
+            object.__setattr__(self, "compute_dtype", src.compute_dtype)
+            object.__setattr__(self, "_engine_args", src._engine_args)
         return self._engine
 
     def pipeline_twin(self, device):
         """A second handle on this model for a second step in flight (tdrn_amd.engine.InFlight): the same parameters and the same
         packed weight blob, its own engine (workspace, lanes, offset-reuse state): `NetEngine.clone()` behind the module interface."""
         import copy
-        twin = copy.copy(self)
-        object.__setattr__(twin, "_engine", self.engine(device).clone())
+        src = self._twin_of or self
+        twin = copy.copy(src)
+        object.__setattr__(twin, "_twin_of", src)             # linked: see _twin_engine (round-5 advisor finding: a twin that only
+        object.__setattr__(twin, "_engine", None)             # held the old blob ran stale weights after a reload of the source)
+        object.__setattr__(twin, "_twin_packs", -1)
         object.__setattr__(twin, "_size_engines", {})
         object.__setattr__(twin, "_dirty", False)
+        twin.engine(device)
         return twin
 
     def engine_for(self, x):
@@ -124,6 +147,7 @@ class EngineModule(nn.Module):
             eng._alloc_weights(device)
         eng.broadcast_weights(src)
         object.__setattr__(self, "_dirty", False)
+        object.__setattr__(self, "_packs", self._packs + 1)
         return eng
 
     def load_weights(self, base_file):

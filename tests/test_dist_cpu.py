@@ -184,3 +184,34 @@ def test_rank_pinning_reads_the_gpus_numa_node_from_sysfs(tmp_path, monkeypatch)
         assert d["pinned"] and os.sched_getaffinity(0) == set(lo)
     finally:
         os.sched_setaffinity(0, before)
+
+
+def _forced_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      TDRN_DIST_FORCE_GROUP="1")
+    r, lr, w = tdist.init(backend="gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and tdist.active()
+    blob = torch.arange(100, dtype=torch.uint8)
+    assert torch.equal(tdist.broadcast_blob(blob.clone()), blob)
+    det = torch.randn(3, 2, 4, 5)
+    got = tdist.gather_results(det, 0, 1)
+    assert len(got) == 1 and torch.equal(got[0], det)
+    assert tdist.gather_results("x", 0, 1) == ["x"]
+    with pytest.raises(ValueError, match="unsupported tensor"):
+        tdist.gather_results(torch.zeros(2, dtype=torch.complex64), 0, 1)
+    assert tdist.max_over_ranks(2.5) == 2.5
+    tdist.barrier()
+    q.put("ok")
+    dist.destroy_process_group()
+
+
+def test_forced_group_at_world_size_one_runs_the_collectives():
+    """TDRN_DIST_FORCE_GROUP=1 (how tests/test_gpu_dist.py::test_rccl_* executes the RCCL branches on one GPU): with it a one-rank
+    group is built and every collective of tdrn_amd.dist runs; without it world size 1 stays collective-free."""
+    assert not tdist.active()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"

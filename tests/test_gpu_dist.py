@@ -133,3 +133,37 @@ def test_bench_py_other_baseline_configs(config, batch):
     if config == 5:
         assert abs(d["clips_per_s"] * 4 - d["value"]) / d["value"] < 1e-3
         assert d["config"]["global_batch"] == batch * 4 and d["trn_mode"] == "batched" and d["trn_static_net_overlapped"] is True
+
+
+def _one_rank_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TDRN_DIST_BACKEND")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TDRN_DIST_FORCE_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def test_rccl_branches_at_world_size_one(tmp_path):
+    """The `nccl` (= RCCL) branches of tdrn_amd/dist.py had run on no GPU before round 6 (every multi-rank test is gloo: RCCL refuses
+    two ranks on one device).  One fresh rank with backend "nccl" and TDRN_DIST_FORCE_GROUP=1 drives init, adopt_broadcast_weights /
+    broadcast_weights, broadcast_blob, gather_results (device tensor, host tensor, empty shard, object, 0-dim, the two unsupported-tensor
+    headers), max_over_ranks and barrier through RCCL on cuda:0 (tests/_rccl_worker.py).  The reference's only multi-GPU code is
+    train.py:157-158 (nn.DataParallel)."""
+    out = tmp_path / "rccl.npz"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), str(out)], env=_one_rank_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, "rc %d\n%s\n%s" % (p.returncode, p.stdout.decode()[-2000:], p.stderr.decode()[-4000:])
+    r = np.load(out)
+    assert r["ok"][0] == 1 and r["wsum"][0] != 0.0
+
+
+def test_bench_py_one_rank_over_rccl():
+    """`bench.py --gpus 1` with a forced process group: the bench's N > 1 branch (weights by RCCL broadcast, barriers and the
+    max-over-ranks all_reduce around every timed repetition) on the backend the driver's 8-GPU run will use."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "4", "--steps", "3", "--warmup", "2", "--reps", "2",
+                        "--no-cpu-baseline", "--no-parity", "--no-modes", "--stream", "0"], env=_one_rank_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["dist_backend"] == "nccl" and d["weights_broadcast_ms"] > 0 and d["value"] > 0

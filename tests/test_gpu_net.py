@@ -1007,6 +1007,35 @@ def test_trn_two_clip_steps_in_flight_equal_one_at_a_time():
     fl.check()
 
 
+def test_pipeline_twin_follows_a_reload_of_its_source():
+    """Round-5 advisor finding: a `pipeline_twin()` kept the blob of the moment it was made -- after load_state_dict /
+    set_compute_dtype / set_plan_flags on the source the two pipelines ran different weights without any error.  The twin now
+    follows its source: it re-clones whenever the source has re-packed (tdrn_amd/model/_base.py _twin_engine)."""
+    net, _ = _build("ssd4scale_vgg", (320, 21, 1024, True, False), seed=0)
+    net.set_compute_dtype("bf16")
+    x = torch.from_numpy(synth.synth_frames(2, 320, seed=5)).to(DEV)
+    twin = net.pipeline_twin(DEV)
+    a, b = [t.clone() for t in net(x)[:2]], [t.clone() for t in twin(x)[:2]]
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    e_old = twin.engine(DEV)
+    # new weights on the SOURCE only
+    sd2 = synth.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 3)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    c, d = [t.clone() for t in net(x)[:2]], [t.clone() for t in twin(x)[:2]]
+    assert not torch.equal(a[0], c[0])                                     # the reload changed the result ...
+    assert all(torch.equal(u, v) for u, v in zip(c, d))                    # ... on both pipelines
+    assert twin.engine(DEV) is not e_old and twin.engine(DEV).weights is net.engine(DEV).weights
+    # a dtype switch and a plan switch on the source reach the twin too; the twin used FIRST re-packs the source
+    net.set_compute_dtype("fp16")
+    d16 = [t.clone() for t in twin(x)[:2]]
+    c16 = [t.clone() for t in net(x)[:2]]
+    assert all(torch.equal(u, v) for u, v in zip(c16, d16)) and not torch.equal(c16[0], c[0])
+    net.set_plan_flags(_lib.PLAN_ONE_STREAM)
+    assert all(torch.equal(u, v) for u, v in zip(net(x)[:2], twin(x)[:2]))
+    # a twin of a twin is a twin of the source
+    assert net.pipeline_twin(DEV)._twin_of is net and twin.pipeline_twin(DEV)._twin_of is net
+
+
 def test_two_steps_in_flight_equal_one_at_a_time():
     """Round 5, the default schedule of bench.py / FrameStream: two whole steps in flight (tdrn_amd.engine.InFlight -- pipeline p =
     its own engine handle, workspace, stream and hipGraph over ONE weight blob).  Every batch's detections are, bit for bit, what

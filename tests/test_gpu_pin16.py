@@ -427,7 +427,11 @@ def test_kernel_choice_never_changes_a_bit(dtype):
         for flags in (_lib.PLAN_NO_CONV_PP, _lib.PLAN_NO_PP_SK, _lib.PLAN_NO_CONV_PP | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_CONV_WS,
                       _lib.PLAN_NO_CONV_WS | _lib.PLAN_NO_FUSE_FIRST, _lib.PLAN_NO_FUSE_FIRST,
                       _lib.PLAN_NO_YGEMM_V2,         # (+ the transform of the deformable heads on its round-3 schedule)
-                      _lib.PLAN_TS_ONE_RANGE):       # (+ the heads over the whole batch at once instead of cache-sized ranges of frames)
+                      _lib.PLAN_TS_ONE_RANGE,        # (+ the heads over the whole batch at once instead of cache-sized ranges of frames)
+                      # (round 6: + conv3x3_patch.hip's tail split -- 64-cout half items in an XCD's last, at most half-filled round --
+                      # against whole items: batch 32 cuts conv2_1 / 2_2 / 3_1 / 3_3, batch 7 conv3_x, 512 px batch 3 conv3_x; with
+                      # every 3x3 layer on that kernel as well)
+                      _lib.PLAN_NO_PATCH_TAIL, _lib.PLAN_NO_PATCH_TAIL | _lib.PLAN_NO_CONV_PP):
             other, _ = _build(VGG[0], args, dtype=dtype, flags=flags)
             got = _outputs(other, x)
             assert len(got) == len(want)
