@@ -178,3 +178,4 @@ def require_cuda(t, name="tensor"):
             "%s must live on the GPU: tdrn_amd runs only through libtdrn_hip.so on an MI355X "
             "(no CPU path; the reference's ConvOffset2dFunction raises here too, "
             "model/networks.py:632-633)" % name)
+

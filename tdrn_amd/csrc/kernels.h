@@ -131,6 +131,10 @@ int launch_softmax_rows(const float *in, float *out, long long R, int C, hipStre
 int launch_offset_conv(const float *loc, long long loc_bs, long long loc_ps, const float *w,
                        const float *bias, float *off, int B, int HW, int n_in, int n_out,
                        hipStream_t s);
+// ... of up to four pyramid levels in one launch (n_in = 12); same arithmetic per output
+struct OffsetProblem { const float *loc; long long loc_bs, loc_ps; const float *w, *bias; float *off; int B, HW, n_out, blk0; };
+struct OffsetMulti { OffsetProblem pr[4]; int n; };
+int launch_offset_conv_multi(const OffsetProblem *pr, int n, hipStream_t s);
 // layout conversions for the API surfaces that are NCHW fp32
 int launch_nchw_to_nhwc(const float *in, void *out, int B, int C, int HW, int Cpad, int dtype,
                         hipStream_t s);   // fp32 NCHW -> DT NHWC (channel-padded with zeros)

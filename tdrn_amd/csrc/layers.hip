@@ -778,6 +778,71 @@ int launch_offset_conv(const float *loc, long long loc_bs, long long loc_ps, con
     return hip_status(hipGetLastError());
 }
 
+// The offset convs of all pyramid levels in ONE launch (round 6: four launches of 16-25 us each -- most of it the launch itself --
+// sat back to back on the ARM side lane).  blockIdx.x = 64-pixel block of problem p (pr[p].blk0 <= blockIdx.x < pr[p + 1].blk0),
+// blockIdx.y = 128-column slice; the body is offset_conv_kernel's, per-output arithmetic and order unchanged (bit-identical).
+__global__ __launch_bounds__(256) void offset_conv_multi_kernel(const OffsetMulti mp)
+{
+    __shared__ float s_w[128 * 16], s_b[128], s_l[64 * 16];
+    const int t = threadIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < mp.n && (int)blockIdx.x >= mp.pr[i].blk0) q = i;
+    const OffsetProblem &pr = mp.pr[q];
+    const int n_in = 12, n_out = pr.n_out;
+    const int oc0 = blockIdx.y * 128;
+    if (oc0 >= n_out) return;
+    const int nc = n_out - oc0 < 128 ? n_out - oc0 : 128;
+    const long long M = (long long)pr.B * pr.HW;
+    const long long m0 = (long long)((int)blockIdx.x - pr.blk0) * 64;
+    for (int i = t; i < nc * n_in; i += 256) s_w[i] = pr.w[oc0 * n_in + i];
+    for (int i = t; i < nc; i += 256) s_b[i] = pr.bias ? pr.bias[oc0 + i] : 0.f;
+    for (int i = t; i < 64 * n_in; i += 256) {
+        const int r = i / n_in, j = i - r * n_in;
+        const long long m = m0 + r;
+        float v = 0.f;
+        if (m < M) {
+            const int b = (int)(m / pr.HW), pix = (int)(m - (long long)b * pr.HW);
+            v = pr.loc[b * pr.loc_bs + pix * pr.loc_ps + j];
+        }
+        s_l[i] = v;
+    }
+    __syncthreads();
+    const int rows = M - m0 < 64 ? (int)(M - m0) : 64;
+    const int total = rows * nc;
+    float *dst = pr.off + m0 * n_out + oc0;
+    for (int idx = t; idx < total; idx += 256) {
+        const int r = idx / nc, o = idx - r * nc;
+        float acc = s_b[o];
+        for (int j = 0; j < n_in; ++j) acc = fmaf(s_w[o * n_in + j], s_l[r * n_in + j], acc);
+        dst[(long long)r * n_out + o] = acc;
+    }
+}
+
+int launch_offset_conv_multi(const OffsetProblem *pr, int n, hipStream_t s)
+{
+    if (n <= 0) return TDRN_OK;
+    if (n > 4) return TDRN_E_ARG;
+    OffsetMulti mp;
+    mp.n = 0;
+    int blocks = 0, max_out = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long M = (long long)pr[i].B * pr[i].HW;
+        if (M <= 0 || pr[i].n_out <= 0) continue;
+        const long long b = (M + 63) / 64;
+        if (blocks + b >= (1ll << 30)) return TDRN_E_UNSUPPORTED;
+        mp.pr[mp.n] = pr[i];
+        mp.pr[mp.n].blk0 = blocks;
+        blocks += (int)b;
+        max_out = pr[i].n_out > max_out ? pr[i].n_out : max_out;
+        ++mp.n;
+    }
+    if (!mp.n) return TDRN_OK;
+    hipLaunchKernelGGL(offset_conv_multi_kernel, dim3((unsigned)blocks, (unsigned)((max_out + 127) / 128)), dim3(256), 0, s, mp);
+    return hip_status(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------------
 // layout conversions (API surfaces are NCHW fp32)
 // ---------------------------------------------------------------------------------------------

@@ -517,13 +517,15 @@ struct tdrn_net {
     {
         int off_t[4];
         cur_lane = 3;                       // ARM heads + offset convs: off the critical path
+        // the four ARM loc heads first, then the four offset convs back to back: consecutive OP_OFFSET ops of a lane run as ONE
+        // launch (round 6: each was a 16-25 us launch of its own between two heads; same arithmetic per output)
+        for (int s = 0; s < 4; ++s) conv(src[s], "arm_loc." + std::to_string(s), bias, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
         for (int s = 0; s < 4; ++s) {
             const std::string ss = std::to_string(s);
-            conv(src[s], "arm_loc." + ss, bias, "", 12, 3, 1, 1, 1, 0, -1, OUT_ARM_LOC, s);
             off_t[s] = offset_conv(s, fm[s], fm[s], "offset." + ss, cfg.multihead ? "offset2." + ss : "", bias,
                                    cfg.def_groups * 18, cfg.def_groups * 50, OUT_ARM_LOC);
-            offsets_out(s, off_t[s], cfg.def_groups * 18);
         }
+        for (int s = 0; s < 4; ++s) offsets_out(s, off_t[s], cfg.def_groups * 18);
         cur_lane = 0;
         for (int s = 0; s < 4; ++s) {
             const std::string ss = std::to_string(s);
@@ -652,13 +654,10 @@ struct tdrn_net {
             // all four levels' offsets first, then the four deformable heads back to back: consecutive OP_DEFORM ops run as ONE
             // launch (the gather kernel is latency-bound per workgroup -- 72 dependent K steps with 8 groups -- so four launches
             // cost four times the one: 4 x 230-330 us -> 330 us at config #5's batch, profiles/r04_cfg5)
-            int ot[4];
-            for (int s = 0; s < 4; ++s) {
-                const std::string ss = std::to_string(s);
-                const int rl = ref_loc_in(s, fm[s], fm[s]);
-                ot[s] = offset_conv(s, fm[s], fm[s], "offset." + ss, "", true, 8 * 18, 0, -1, rl);
-                offsets_out(s, ot[s], 8 * 18);
-            }
+            int ot[4], rl[4];
+            for (int s = 0; s < 4; ++s) rl[s] = ref_loc_in(s, fm[s], fm[s]);
+            for (int s = 0; s < 4; ++s) ot[s] = offset_conv(s, fm[s], fm[s], "offset." + std::to_string(s), "", true, 8 * 18, 0, -1, rl[s]);     // (one launch)
+            for (int s = 0; s < 4; ++s) offsets_out(s, ot[s], 8 * 18);
             for (int s = 0; s < 4; ++s) {
                 const std::string ss = std::to_string(s);
                 deform_heads(src[s], ot[s], s, 8, "arm_loc." + ss, "arm_conf." + ss, "", "", 0, OUT_ARM_LOC);
@@ -1278,6 +1277,8 @@ struct tdrn_net {
             if (d.kind == OP_DEFORM && d.y_t >= 0 && !ygemm_supported(d.Cin, d.y_cols, cfg.dtype)) ts_tap_major = 0;
         int ts_cs[4] = {0, 0, 0, 0}, ts_op[4] = {-1, -1, -1, -1};
         int n_dargs = 0;
+        OffsetProblem oq[4];                                // consecutive offset convs of one lane: one launch (layers.hip)
+        int oq_op[4], n_oq = 0;
         bool dwpw_done = false;
         const bool reuse_offsets = cfg.deform && io->reserved[0] != nullptr;
         if (reuse_offsets && (offs_ws != ws || offs_batch != B)) return TDRN_E_STATE;
@@ -1321,7 +1322,9 @@ struct tdrn_net {
                 }
             }
             const bool deform_batched = o.kind == OP_DEFORM && oi + 1 < ops.size() && ops[oi + 1].kind == OP_DEFORM && n_dargs < 3;
-            if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) { TDRN_HIP_TRY(hipEventRecord(ev[evi], s)); }
+            const bool offset_batched = o.kind == OP_OFFSET && oi + 1 < ops.size() && ops[oi + 1].kind == OP_OFFSET && n_oq < 3 &&
+                                        (lanes ? ops[oi + 1].lane : 0) == lane;
+            if (profile && !(o.kind == OP_DEFORM && n_dargs > 0) && !(o.kind == OP_OFFSET && n_oq > 0)) { TDRN_HIP_TRY(hipEventRecord(ev[evi], s)); }
             int rc = TDRN_OK;
             switch (o.kind) {
                 case OP_FIRST:
@@ -1463,8 +1466,19 @@ struct tdrn_net {
                     if (o.in >= 0) { loc = (const float *)tptr(ws, o.in, B); bs = (long long)o.hw * 12; ps = 12; }
                     else { loc = io->arm_loc + (size_t)scale_off[o.scale] * 4; bs = (long long)P * 4; ps = 12; }
                     // (offsets from ref_loc maps exist for the Bk key frames only; from the net's own ARM loc for every sample)
-                    rc = launch_offset_conv(loc, bs, ps, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
-                                            (float *)tptr(ws, o.out, B), o.in >= 0 ? Bk : B, o.hw, 12, o.off_n, s);
+                    oq[n_oq] = OffsetProblem{loc, bs, ps, (const float *)(wb + o.w_off), (const float *)(wb + o.b_off),
+                                             (float *)tptr(ws, o.out, B), o.in >= 0 ? Bk : B, o.hw, o.off_n, 0};
+                    oq_op[n_oq++] = (int)oi;
+                    if (!offset_batched) {
+                        rc = launch_offset_conv_multi(oq, n_oq, s);
+                        if (rc != TDRN_OK) break;
+                        // the outputs of the launch's earlier members become visible HERE, not where their ops stood
+                        for (int i = 0; i + 1 < n_oq; ++i) {
+                            const int t_ = ops[oq_op[i]].out;
+                            if (lanes && t_ >= 0 && tensor_shared[t_]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[t_], s));
+                        }
+                        n_oq = 0;
+                    }
                     break;
                 }
                 case OP_DEFORM: {
@@ -1616,9 +1630,9 @@ struct tdrn_net {
             }
             if (rc != TDRN_OK) return rc;
             offset_ops_enqueued += o.kind == OP_OFFSET;
-            if (lanes && o.out >= 0 && tensor_shared[o.out]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.out], s));
+            if (lanes && o.out >= 0 && tensor_shared[o.out] && !(o.kind == OP_OFFSET && n_oq > 0)) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.out], s));
             if (lanes && o.pool_t >= 0 && tensor_shared[o.pool_t]) TDRN_HIP_TRY(hipEventRecord(tensor_ev[o.pool_t], s));
-            if (profile && !(o.kind == OP_DEFORM && n_dargs > 0)) {
+            if (profile && !(o.kind == OP_DEFORM && n_dargs > 0) && !(o.kind == OP_OFFSET && n_oq > 0)) {
                 TDRN_HIP_TRY(hipEventRecord(ev[evi + 1], s));
                 ev_stat.push_back(o.stat);
                 ev_op.push_back((int)oi);
@@ -1650,10 +1664,12 @@ struct tdrn_net {
             memset(&stats[i], 0, sizeof(stats[i]));
             strncpy(stats[i].name, kStatNames[i], sizeof(stats[i].name) - 1);
         }
-        bool prev_deform = false;
+        bool prev_deform = false, prev_offset = false;
         for (const Op &o : ops) {
-            if (!(o.kind == OP_DEFORM && prev_deform) && !(o.kind == OP_CONV && o.chain > 0) && !(o.kind == OP_CONV && o.fused_dw)) stats[o.stat].launches += 1;
+            if (!(o.kind == OP_DEFORM && prev_deform) && !(o.kind == OP_OFFSET && prev_offset) && !(o.kind == OP_CONV && o.chain > 0) &&
+                !(o.kind == OP_CONV && o.fused_dw)) stats[o.stat].launches += 1;
             prev_deform = o.kind == OP_DEFORM;
+            prev_offset = o.kind == OP_OFFSET;
             stats[o.stat].flops += o.flops * last_batch;
             stats[o.stat].bytes += o.bytes * last_batch;
         }

@@ -397,8 +397,14 @@ class InFlight(object):
         steps, the best pair kept.  ~16 x steps steps on whatever the resident batches hold; results are unaffected (the same
         launches in the same per-pipeline order).  Returns {"i,j": ms per step} and keeps the best pair."""
         import itertools
+        import os
         import time
         if self.graph or self.n < 2 or self.n > candidates:      # (replays launched on picked streams were tried: 11.3k frames/s whatever the pair)
+            return None
+        # (round 6, measured and rejected as deterministic replacements of this calibration -- profiles/r06_experiments.md: the pipelines on
+        # streams of different PRIORITY 10.5k frames/s, on dedicated hardware queues (hipExtStreamCreateWithCUMask, all CUs) 10.6k, on
+        # the streams InFlight creates 11.2k, calibrated 12.4-12.5k: what the good pairs have in common is not "different queues")
+        if os.environ.get("TDRN_INFLIGHT_PICK") == "none":
             return None
         cands = [torch.cuda.Stream(self.dev) for _ in range(candidates)]
         nb = len(self.batches)
