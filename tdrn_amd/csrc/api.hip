@@ -50,7 +50,7 @@ int deform_plan(int N, int Cin, int H, int W, int Cout, int kH, int kW, int dH, 
 
 extern "C" {
 
-const char *tdrn_version(void) { return "tdrn_hip 0.4 (gfx950)"; }
+const char *tdrn_version(void) { return "tdrn_hip 0.6 (gfx950)"; }
 
 const char *tdrn_error_string(int code)
 {

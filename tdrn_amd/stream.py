@@ -76,9 +76,13 @@ class FrameStream(object):
         # copy_in="own": batch k + 2's frames go to the device on the stream of the pipeline that will run them, right behind step k of
         # that pipeline (AHEAD is a multiple of the pipeline count) -- no copy-in stream, no events between it and the steps; the
         # pipeline pauses for the copy (0.35 ms at batch 32) while the other pipeline keeps the chip busy
-        if copy_in not in ("stream", "own") or (copy_in == "own" and AHEAD % NP):
-            raise ValueError("copy_in must be 'stream' or 'own' (own: the pipeline count has to divide %d)" % AHEAD)
-        self.copy_in = copy_in
+        # copy_in="prio" (round 6): copy streams as with "stream", but created with HIGH PRIORITY and not calibrated -- HIP keeps the
+        # hardware queues of a priority level apart, so the copies cannot sit behind a compute lane's kernels in a shared in-order queue
+        # (the reason "stream" needs its calibration), and a stream that only carries DMA takes nothing from the compute lanes
+        if copy_in not in ("stream", "own", "prio") or (copy_in == "own" and AHEAD % NP):
+            raise ValueError("copy_in must be 'stream', 'prio' or 'own' (own: the pipeline count has to divide %d)" % AHEAD)
+        self.copy_priority = copy_in == "prio"
+        self.copy_in = "stream" if copy_in == "prio" else copy_in
 
         def make_step(eng, det):
             def one_step(u8, out=None):
@@ -120,8 +124,8 @@ class FrameStream(object):
             self.dev_out.append(out)
         if not self.graph:
             self.dev_out = [torch.empty_like(probe) for _ in range(slots)]     # (the step's result is copied here: 2.7 MB on the device)
-        self._in_stream = torch.cuda.Stream(dev)
-        self._out_stream = torch.cuda.Stream(dev)
+        self._in_stream = torch.cuda.Stream(dev, priority=-1) if self.copy_priority else torch.cuda.Stream(dev)
+        self._out_stream = torch.cuda.Stream(dev, priority=-1) if self.copy_priority else torch.cuda.Stream(dev)
         self.ev_in = [torch.cuda.Event() for _ in range(slots)]        # slot's frames are on the device
         self.ev_step = [torch.cuda.Event() for _ in range(slots)]      # slot's step has run (its device input is free again)
         self.ev_out = [torch.cuda.Event() for _ in range(slots)]       # slot's detections are on the host (its device output is free)
@@ -135,7 +139,7 @@ class FrameStream(object):
         if calibrate:
             if not self.graph and NP == 2:
                 self._pick_pipeline_streams()
-            if self.copy_in != "own":                    # (own: there are no copy streams to place)
+            if self.copy_in != "own" and not self.copy_priority:     # (own: there are no copy streams to place; prio: placed by construction)
                 self._pick_streams()
 
     def _pick_pipeline_streams(self, candidates=4, steps=6):
