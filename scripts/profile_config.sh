@@ -7,7 +7,7 @@
 #   trace_graph/            rocprofv3 --kernel-trace --stats of the hipGraph replay (what the line times)
 #   pmc_fetch/ pmc_write/   rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, each in its own run with --kernel-trace only
 CFG=${1:-4}
-OUT=${2:-gpurun_out/r05_cfg$CFG}
+OUT=${2:-gpurun_out/r06_cfg$CFG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py --config $CFG > $OUT/bench.json 2> $OUT/bench.err

@@ -9,7 +9,7 @@
 #   trace_graph/          the same of `bench.py --graph 1`                  (the hipGraph REPLAY: what the bench line times)
 #   pmc_fetch/ pmc_write/ rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE           (HBM-side traffic per dispatch)
 #   pmc_sq/               rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE              (wave cycles, waits, matrix-pipe busy, LDS conflicts, clock)
-OUT=${1:-gpurun_out/r05_final}
+OUT=${1:-gpurun_out/r06_final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err

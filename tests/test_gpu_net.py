@@ -1085,6 +1085,25 @@ def test_two_steps_in_flight_equal_one_at_a_time():
             for j in range(NB):
                 assert torch.equal(fl.output(j), want[j]), ("picked streams", j)
             fl.check()
+            # a consumer on ANOTHER stream that only waits for an event: the eager outputs are fresh allocations of the pipeline's stream,
+            # so it asks for them with consumer=<its stream> (record_stream on every tensor; round-5 advisor finding) -- the next
+            # launches of the same batch must not recycle the memory under it
+            side = torch.cuda.Stream(DEV)
+            for k in range(NB):
+                fl.launch(k)
+            copies = []
+            for j in range(NB):
+                ev = torch.cuda.Event()
+                ev.record(fl.stream_of(j))
+                side.wait_event(ev)
+                out_j = fl.output(j, consumer=side)
+                with torch.cuda.stream(side):
+                    copies.append(out_j.clone())
+            for k in range(2 * NB):                      # (re-launches that replace every output while `side` may still be copying)
+                fl.launch(k)
+            fl.sync()
+            for j in range(NB):
+                assert torch.equal(copies[j], want[j]), ("consumer stream", j)
         else:
             assert fl.pick_streams() is None             # (graph pipelines: the streams are part of the capture)
     assert (want[0][..., 0] > 0).any()
