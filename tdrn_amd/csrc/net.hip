@@ -713,12 +713,16 @@ struct tdrn_net {
                 return false;
             };
             int victim = -1;
-            for (size_t i = 2; i < ops.size() && victim < 0; ++i)
+            for (size_t i = 2; i < ops.size() && victim < 0; ++i) {
+                // (a main-lane layer of the trunk: it runs behind ops 0 / 1 in stream order; an op that does not depend on the trunk --
+                // the TRN nets' ref_loc conversions on a side lane -- could otherwise write its output while the copy is still being read)
+                if (ops[i].lane != 0 || !(ops[i].kind == OP_CONV || ops[i].kind == OP_DW || ops[i].kind == OP_POOL) || ops[i].in < 0) continue;
                 for (int t : {ops[i].out, ops[i].pool_t}) {
                     if (t < 0 || victim >= 0 || touched_early(t)) continue;
                     const Tensor &v = tensors[t];
                     if (align_up((size_t)v.Cpad * v.H * v.W * (v.f32 ? 4 : es), 256) >= need) victim = t;
                 }
+            }
             if (victim >= 0) {
                 Tensor t;
                 t.C = 3; t.H = cfg.size; t.W = cfg.size; t.f32 = true; t.Cpad = 3; t.off = tensors[victim].off;
