@@ -478,13 +478,15 @@ struct Pw1x1Params {
     int m_tiles, n_tiles, items;
     int ablate;                    // diagnostics (TDRN_PW_ABLATE): 1 no pixel DMA, 2 no weight DMA, 4 no LDS reads / MFMA, 8 no stores
     int n_major;                   // item = nt * m_tiles + mt instead of mt * n_tiles + nt (see the kernel)
+    int stagger;                   // experiment (TDRN_PW_STAGGER=1): group 1 issues a unit's LDS-DMA pieces BETWEEN its two MFMA halves, group 0 in front of them
+    int tail_split;                // an XCD's last, sparsely filled round of items runs as 64- or 128-cout sub-items (see the kernel)
 };
 
 template <typename DT>
 __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
 {
     constexpr int ES = 2, P16 = 8;
-    constexpr int BN = 256, BNH = 128, WC = 4;
+    constexpr int BN = 256, WC = 4;
     // LDS: THREE pixel-operand buffers (the activations stream from HBM / the Infinity Cache: ~2 us under load, more than one
     // chunk's 32 MFMAs -- with one chunk of prefetch the kernel ran at conv_igemm's speed) + two weight buffers (L2 hits) = 160 KiB;
     // the epilogue's staging strips live in the pixel buffer that died with the item's last chunk
@@ -508,9 +510,34 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     int avail = p.items - xcd * per_xcd;
     avail = avail < per_xcd ? avail : per_xcd;
     avail = avail < 0 ? 0 : avail;
-    const int n_items = avail > slot ? (avail - slot + istride - 1) / istride : 0;
-    if (n_items == 0) return;
+    int n_full = avail > slot ? (avail - slot + istride - 1) / istride : 0;
     const int item0 = xcd * per_xcd + slot;
+    // ---- tail split (round 6; conv3x3_patch.hip has the same idea).  800 items on 256 workgroups are 3.125 rounds: after three rounds an
+    // XCD has 4 items left for its 32 workgroups and the launch's last quarter runs on an eighth of the chip (the five 512 -> 512 layers of
+    // config 4, 256 -> 512, ...).  When the XCD's last round is at most a quarter (half) filled, its items are cut ALONG THE COUTS into
+    // four 64-cout (two 128-cout) sub-items, one per workgroup: the same eight waves with one (two) 32-cout accumulator tiles each, a
+    // quarter (half) of the weight rows, bias and stores, the same pixel rows.  Every output element sees the same MFMA rows in the same
+    // K order: bit-identical whatever the batch does to the cut (TDRN_PLAN_NO_PATCH_TAIL / TDRN_PATCH_TAIL=0 keep whole items).
+    int n_tail = 0, tail_item = 0, tail_c0 = 0, tail_wcn = WC;
+    if (p.tail_split && avail > 0) {
+        const int full = avail / istride, rem = avail - full * istride;
+        const int f = (full > 0 && rem > 0) ? (4 * rem <= istride ? 4 : (2 * rem <= istride ? 2 : 0)) : 0;
+        if (f) {
+            n_full = full;
+            if (slot < f * rem) {
+                n_tail = 1;
+                tail_item = xcd * per_xcd + full * istride + slot / f;
+                tail_wcn = WC / f;
+                tail_c0 = (slot % f) * (BN / f);
+            }
+        }
+    }
+    const int n_items = n_full + n_tail;
+    if (n_items == 0) return;
+    // element i of this workgroup's sequence: item, first cout inside its 256-cout tile, 32-cout accumulator tiles per wave
+    auto seq_item = [&](int i) -> int { return i < n_full ? item0 + i * istride : tail_item; };
+    auto seq_c0 = [&](int i) -> int { return i < n_full ? 0 : tail_c0; };
+    auto seq_wcn = [&](int i) -> int { return i < n_full ? WC : tail_wcn; };
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane(dp_lds_addr(smem));
     // item numbering: pixel-tile major by default -- the cout tiles of one pixel tile are neighbouring items of ONE XCD, dealt to
     // neighbouring workgroups at the same time, so the pixel rows (the operand that streams from HBM) cross the fabric once; the
@@ -522,11 +549,11 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     // one chunk of an operand: wave w stages pixel rows [8(w + 8k), +8) / its group's weight rows, k = 0..3 (4 pieces each);
     // rows past M re-read the last row (their outputs are never stored)
     const unsigned rowb = (unsigned)(p.Cin * ES);
-    auto stage_a = [&](int item, int c, int abuf) {
+    auto stage_a = [&](int i, int c, int abuf) {
         if (p.ablate & 1) return;
         const int ln = opaque_lane();
         const int lrow = ln >> 3, pc = ln & 7;
-        const int mt = mt_of(item);
+        const int mt = mt_of(seq_item(i));
         const unsigned lc = (unsigned)((pc ^ ((4 * wave + (lrow >> 1)) & 7)) << 4) + (unsigned)(c * 128);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -535,22 +562,24 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
             dp_glds16(p.in, (unsigned)m * rowb + lc, __builtin_amdgcn_readfirstlane(smem_lds + abuf * ABYTES + (wave + 8 * k) * 1024));
         }
     };
-    auto stage_w = [&](int item, int c, int wbuf) {
+    auto stage_w = [&](int i, int c, int wbuf) {
         if (p.ablate & 2) return;
         const int ln = opaque_lane();
         const int lrow = ln >> 3, pc = ln & 7;
-        const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane(nt_of(item) * BN * p.Cin * ES + c * 128);
-        const unsigned wo = (unsigned)((grp * 128 + cw * 8 + lrow) * p.Cin * ES) + (unsigned)(((pc ^ ((4 * cw + (lrow >> 1)) & 7)) << 4));
+        const int wcn = seq_wcn(i);                     // my group's rows: 32 wcn of them, behind the (sub-)item's first cout
+        const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane((nt_of(seq_item(i)) * BN + seq_c0(i)) * p.Cin * ES + c * 128);
+        const unsigned wo = (unsigned)((grp * 32 * wcn + cw * 8 + lrow) * p.Cin * ES) + (unsigned)(((pc ^ ((4 * cw + (lrow >> 1)) & 7)) << 4));
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            dp_glds16(p.w + woff, wo + (unsigned)k * (32u * rowb), __builtin_amdgcn_readfirstlane(smem_lds + OFF_W + wbuf * WBYTES + grp * (WBYTES / 2) + (cw + 4 * k) * 1024));
+            if (k < wcn)
+                dp_glds16(p.w + woff, wo + (unsigned)k * (32u * rowb), __builtin_amdgcn_readfirstlane(smem_lds + OFF_W + wbuf * WBYTES + grp * (WBYTES / 2) + (cw + 4 * k) * 1024));
     };
     const int n_units = n_items * nchunks;
     // (item, chunk) of unit u + d, advanced incrementally (no division in the loop)
-    struct Cur { int item, c; };
+    struct Cur { int item, c; };                        // (item = index into this workgroup's sequence)
     auto next_of = [&](Cur q) -> Cur {
         Cur r = q;
-        if (++r.c == nchunks) { r.c = 0; r.item += istride; }
+        if (++r.c == nchunks) { r.c = 0; r.item += 1; }
         return r;
     };
 
@@ -563,7 +592,8 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[ci][pt][e] = 0.f;
     };
-    auto mma_phase = [&](int abuf, int wbuf) {
+    auto mma_phase = [&](auto wcn_tag, int abuf, int wbuf, int h0 = 0, int h1 = 2) {
+        constexpr int WCN = decltype(wcn_tag)::value;   // accumulator tiles per wave along the couts: 4 (whole item), 2, 1 (tail sub-items)
         if (p.ablate & 4) return;
         const int ln = opaque_lane();
         const int r32 = ln & 31, hh = ln >> 5;
@@ -576,19 +606,20 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            u32x4 wf[WC][2], pf[2][2];
+            if (half < h0 || half >= h1) continue;
+            u32x4 wf[WCN][2], pf[2][2];
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 const unsigned kx = (unsigned)((2 * half + k2) << 5);
 #pragma unroll
-                for (int ci = 0; ci < WC; ++ci) wf[ci][k2] = *(const u32x4 *)(smem + ((wa ^ kx) + ci * 4096));
+                for (int ci = 0; ci < WCN; ++ci) wf[ci][k2] = *(const u32x4 *)(smem + ((wa ^ kx) + ci * 4096));
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) pf[pt][k2] = *(const u32x4 *)(smem + (pa[pt] ^ kx));
             }
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-                for (int ci = 0; ci < WC; ++ci)
+                for (int ci = 0; ci < WCN; ++ci)
 #pragma unroll
                     for (int pt = 0; pt < 2; ++pt) MmaDP<DT>::run(wf[ci][k2], pf[pt][k2], acc[ci][pt]);
         }
@@ -597,9 +628,10 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     // it), parked in a wave-private LDS copy behind the staging strips for the epilogue's rounds.  (Read from global inside the
     // rounds -- eight rounds, sixteen loads each -- the epilogue cost 30 us of a 105-us launch.)
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto fetch_bias = [&](int item) {
+    auto fetch_bias = [&](int i) {
         const int ln = opaque_lane();
-        if (ln < 32) bias4 = *(const f32x4 *)(p.bias + nt_of(item) * BN + grp * BNH + 4 * ln);
+        const int wcn = seq_wcn(i);
+        if (ln < 8 * wcn) bias4 = *(const f32x4 *)(p.bias + nt_of(seq_item(i)) * BN + seq_c0(i) + grp * 32 * wcn + 4 * ln);
     };
     // Epilogue of one item.  Rounds are (pixel tile, 64-cout half): EVERY lane stages its pixel row's 64 couts (8 quads) into a
     // wave-private strip of 32 rows x 128 B, then the wave copies the strip out as whole 128-byte lines.  (A first version staged
@@ -609,7 +641,9 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     constexpr int SST = 64 * ES + 16;                   // strip row stride: 64 couts + 16 B against bank conflicts
     constexpr int SBYTES = 32 * SST;                    // 4.5 KiB per wave
     static_assert(4 * (SBYTES + 512) <= ABYTES && 4 * (SBYTES + 512) <= WBYTES, "strips + bias copies fit the dead buffers");
-    auto epilogue = [&](int item, int dead_abuf, int dead_wbuf) {
+    auto epilogue = [&](auto wcn_tag, int i, int dead_abuf, int dead_wbuf) {
+        constexpr int WCN = decltype(wcn_tag)::value;
+        const int item = seq_item(i);
         char *base = (wave < 4 ? smem + dead_abuf * ABYTES : smem + OFF_W + dead_wbuf * WBYTES) + (wave & 3) * (SBYTES + 512);
         char *stg = base, *sbias = base + SBYTES;
         const int ln = opaque_lane();
@@ -617,21 +651,24 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
         DP_LGKM0();
         __builtin_amdgcn_wave_barrier();
         const int r32 = ln & 31, hh = ln >> 5;
-        const int n0 = nt_of(item) * BN;
+        const int n0 = nt_of(item) * BN + seq_c0(i);
         const long long pix0 = (long long)mt_of(item) * 256 + cw * 64;
         const int orow = ln >> 3, och = ln & 7;         // copy-out: 8 lanes x 16 B = one 128-byte line of a pixel row, 8 rows per pass
+        constexpr int NCH = (WCN + 1) / 2;              // rounds of 64 couts (a 32-cout wave tile fills half a strip row)
+        constexpr int NC2 = WCN >= 2 ? 2 : 1;
 #pragma unroll
-        for (int chalf = 0; chalf < 2; ++chalf) {
-            f32x4 bv[2][4];
+        for (int chalf = 0; chalf < NCH; ++chalf) {
+            f32x4 bv[NC2][4];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
+            for (int c2 = 0; c2 < NC2; ++c2)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bv[c2][g] = *(const f32x4 *)(sbias + ((2 * chalf + c2) * 32 + 8 * g + 4 * hh) * 4);
-            const int my_c = n0 + grp * BNH + chalf * 64 + och * P16;
+            const int my_c = n0 + grp * (32 * WCN) + chalf * 64 + och * P16;
+            const bool och_ok = och * P16 < 32 * NC2;   // (a 32-cout tile: the row's first 64 bytes only)
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
+                for (int c2 = 0; c2 < NC2; ++c2)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float q4[4];
@@ -648,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
                 for (int k = 0; k < 4; ++k) {
                     const int row = orow + 8 * k;
                     const long long gp = pix0 + pt * 32 + row;
-                    if (gp < p.M && my_c < p.Cout && !(p.ablate & 8))
+                    if (gp < p.M && my_c < p.Cout && och_ok && !(p.ablate & 8))
                         *(u32x4 *)(p.out + ((size_t)gp * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SST + och * 16);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -658,36 +695,63 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
 
     // ---- pipeline: in iteration u the weights of unit u+1 and the pixels of unit u+2 are issued, in that order: the in-order
     // counter then lets the four youngest pieces (pixels, needed one iteration later) stay in flight
-    Cur q0{item0, 0};
+    Cur q0{0, 0};
     Cur q1 = next_of(q0), q2 = next_of(q1);
     stage_w(q0.item, q0.c, 0);
     stage_a(q0.item, q0.c, 0);
     if (n_units > 1) stage_a(q1.item, q1.c, 1);
     zero_acc();
     int abuf = 0, wbuf = 0;
-#pragma unroll 1
-    for (int u = 0; u < n_units; ++u) {
+    // One unit = one 64-channel chunk of one (sub-)item.  The unit body is a generic lambda instantiated once per accumulator-tile count
+    // and run by SEPARATE loops (whole items first, then this workgroup's tail sub-item): with the three MFMA bodies as alternatives inside
+    // one loop hipcc gave each its own accumulator registers and copied all 128 of them around every unit (first build of the tail split:
+    // every pointwise layer 3-4x slower, tail split on or off).
+    typedef std::integral_constant<int, 4> w4_t;
+    typedef std::integral_constant<int, 2> w2_t;
+    typedef std::integral_constant<int, 1> w1_t;
+    auto unit = [&](auto wtag, int u) {
         // unit u's operands have landed: its weights were issued BEFORE the (younger) pixel pieces of unit u+1
         if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_BAR();                                       // ... everybody's; and every wave has left the MFMAs of unit u-1
-        if (u + 1 < n_units) stage_w(q1.item, q1.c, wbuf ^ 1);
-        if (u + 2 < n_units) stage_a(q2.item, q2.c, abuf == 0 ? 2 : abuf - 1);     // (= the buffer of unit u-1)
+        const bool late = p.stagger && grp == 1;        // (wave-uniform; experiment: group 1 issues its pieces between its two MFMA halves)
+        if (!late) {
+            if (u + 1 < n_units) stage_w(q1.item, q1.c, wbuf ^ 1);
+            if (u + 2 < n_units) stage_a(q2.item, q2.c, abuf == 0 ? 2 : abuf - 1);     // (= the buffer of unit u-1)
+        }
         const bool last = q0.c + 1 == nchunks;
         if (last) fetch_bias(q0.item);
         __builtin_amdgcn_s_setprio(1);
-        mma_phase(abuf, wbuf);
+        mma_phase(wtag, abuf, wbuf, 0, 1);
+        if (late) {
+            if (u + 1 < n_units) stage_w(q1.item, q1.c, wbuf ^ 1);
+            if (u + 2 < n_units) stage_a(q2.item, q2.c, abuf == 0 ? 2 : abuf - 1);
+        }
+        mma_phase(wtag, abuf, wbuf, 1, 2);
         __builtin_amdgcn_s_setprio(0);
         if (last) {
             DP_LGKM0();
             DP_BAR();                                   // every wave has read unit u's pixels: that buffer is the staging area now
-            epilogue(q0.item, abuf, wbuf);
+            epilogue(wtag, q0.item, abuf, wbuf);
             zero_acc();
             DP_LGKM0();
         }
         q0 = q1; q1 = q2; q2 = next_of(q2);
         abuf = abuf == 2 ? 0 : abuf + 1;
         wbuf ^= 1;
+    };
+    const int n_main = n_full * nchunks;
+    int u = 0;
+#pragma unroll 1
+    for (; u < n_main; ++u) unit(w4_t{}, u);
+    if (n_tail) {
+        if (tail_wcn == 2) {
+#pragma unroll 1
+            for (; u < n_units; ++u) unit(w2_t{}, u);
+        } else {
+#pragma unroll 1
+            for (; u < n_units; ++u) unit(w1_t{}, u);
+        }
     }
 }
 
@@ -788,6 +852,12 @@ int launch_pw1x1(const ConvArgs &a, hipStream_t s)
     static int nmajor = -1;
     if (nmajor < 0) { const char *e = getenv("TDRN_PW_NMAJOR"); nmajor = e ? atoi(e) : 0; }
     p.n_major = nmajor;
+    static int stag = -1;
+    if (stag < 0) { const char *e = getenv("TDRN_PW_STAGGER"); stag = e ? atoi(e) : 0; }
+    p.stagger = stag;
+    static int tail = -1;
+    if (tail < 0) { const char *e = getenv("TDRN_PATCH_TAIL"); tail = e ? atoi(e) : 1; }
+    p.tail_split = tail && !(a.kdisable & 1024);     // (TDRN_PLAN_NO_PATCH_TAIL; pixel-tile-major items only: the sub-items of a tile are neighbours)
     const int grid = p.items >= 256 ? 256 : ((p.items + 7) / 8) * 8;
     if (a.dtype == TDRN_BF16) hipLaunchKernelGGL((pw1x1_kernel<bf16_t>), dim3(grid), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((pw1x1_kernel<f16_t>), dim3(grid), dim3(512), 0, s, p);

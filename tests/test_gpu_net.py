@@ -357,9 +357,17 @@ def test_config4_drn_mobilenet_batch64(dtype):
     net, sd = _build("dualrefinedet_mobilenet", (320, 21, 1, True))
     net.set_compute_dtype(dtype)
     x = torch.from_numpy(synth.synth_frames(64, 320, seed=35)).to(DEV)
-    arm, odm, conf = _rows_equal_single_runs(net, x, (0, 33, 63))
+    # (rows 7, 15, 63: frames whose last pixel tiles are TAIL SUB-ITEMS of pw1x1_kernel at this batch -- 800 items of a 512 -> 512 layer
+    # are 3.125 rounds; an XCD's last four items run as sixteen 64-cout quarter items, round 6 -- against conv_igemm at batch 1)
+    arm, odm, conf = _rows_equal_single_runs(net, x, (0, 7, 15, 33, 63))
     assert arm.shape == (64, 6375, 4) and conf.shape == (64 * 6375, 21)
     _check_drift("dualrefinedet_mobilenet", dtype, net, sd, synth.synth_frames(1, 320, seed=5))
+    # whole items only: the same bits
+    other, _ = _build("dualrefinedet_mobilenet", (320, 21, 1, True))
+    other.set_compute_dtype(dtype)
+    other.set_plan_flags(_lib.PLAN_NO_PATCH_TAIL)
+    for u, v in zip(_split_outputs(other(x)), (arm, odm, conf)):
+        assert u is None or torch.equal(u, v)
 
 
 @pytest.mark.parametrize("dtype16", ["fp16", "bf16"])
