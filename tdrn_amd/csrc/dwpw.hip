@@ -478,7 +478,7 @@ struct Pw1x1Params {
     int m_tiles, n_tiles, items;
     int ablate;                    // diagnostics (TDRN_PW_ABLATE): 1 no pixel DMA, 2 no weight DMA, 4 no LDS reads / MFMA, 8 no stores
     int n_major;                   // item = nt * m_tiles + mt instead of mt * n_tiles + nt (see the kernel)
-    int stagger;                   // experiment (TDRN_PW_STAGGER=1): group 1 issues a unit's LDS-DMA pieces BETWEEN its two MFMA halves, group 0 in front of them
+    int stagger;                   // group 1 issues a unit's LDS-DMA pieces BETWEEN its two MFMA halves, group 0 in front of them (TDRN_PW_STAGGER=0: both in front)
     int tail_split;                // an XCD's last, sparsely filled round of items runs as 64- or 128-cout sub-items (see the kernel)
 };
 
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
         if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DP_BAR();                                       // ... everybody's; and every wave has left the MFMAs of unit u-1
-        const bool late = p.stagger && grp == 1;        // (wave-uniform; experiment: group 1 issues its pieces between its two MFMA halves)
+        const bool late = p.stagger && grp == 1;        // (wave-uniform: group 1 issues its pieces between its two MFMA halves)
         if (!late) {
             if (u + 1 < n_units) stage_w(q1.item, q1.c, wbuf ^ 1);
             if (u + 2 < n_units) stage_a(q2.item, q2.c, abuf == 0 ? 2 : abuf - 1);     // (= the buffer of unit u-1)
@@ -853,7 +853,10 @@ int launch_pw1x1(const ConvArgs &a, hipStream_t s)
     if (nmajor < 0) { const char *e = getenv("TDRN_PW_NMAJOR"); nmajor = e ? atoi(e) : 0; }
     p.n_major = nmajor;
     static int stag = -1;
-    if (stag < 0) { const char *e = getenv("TDRN_PW_STAGGER"); stag = e ? atoi(e) : 0; }
+    // (round 6, default on: wave group 1 issues a unit's eight LDS-DMA pieces between its two MFMA halves, group 0 in front of them, so
+    // the two waves of a SIMD no longer issue and multiply in lockstep: -2 % on the 8-chunk layers, -9...-10 % on the 16-chunk ones
+    // (512 -> 1024, 1024 -> 1024 at 20 x 20); same arithmetic, same bits.  Round 4 had moved only the pixel pieces behind ALL the MFMAs: nothing.)
+    if (stag < 0) { const char *e = getenv("TDRN_PW_STAGGER"); stag = e ? atoi(e) : 1; }
     p.stagger = stag;
     static int tail = -1;
     if (tail < 0) { const char *e = getenv("TDRN_PATCH_TAIL"); tail = e ? atoi(e) : 1; }
