@@ -184,7 +184,9 @@ __device__ __forceinline__ void igemm_tile(const ConvParams &p, const int wg, co
 
     int tr = 0, tq = 0, c0 = 0, kofs = 0;   // current tap (row, col), channel offset, K offset
     auto stage = [&](int buf) {
+#ifdef TDRN_DEV_ABLATE
         if (p.ablate & 1) return;
+#endif
         char *sb = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -239,7 +241,9 @@ __device__ __forceinline__ void igemm_tile(const ConvParams &p, const int wg, co
     const int wm = wave % WGM, wn = wave / WGM;
     const int prow0 = wm * (WP * 32) + r32, crow0 = wn * (WC * 32) + r32;
     auto compute = [&](int buf) {
+#ifdef TDRN_DEV_ABLATE
         if (p.ablate & 2) return;
+#endif
         const char *wsb = smem + buf * STAGE;
         const char *psb = wsb + BN * 128;
 #pragma unroll

@@ -482,6 +482,18 @@ struct Pw1x1Params {
     int tail_split;                // an XCD's last, sparsely filled round of items runs as 64- or 128-cout sub-items (see the kernel)
 };
 
+// (developer builds only: the ablation switches are compiled out of the product -- a RUNTIME branch around the MFMA block of a K loop made
+// hipcc keep the accumulators in a second register set and copy all of them around every step in conv_igemm.hip, round 6)
+__device__ __forceinline__ bool pw_store_on(const Pw1x1Params &p)
+{
+#ifdef TDRN_DEV_ABLATE
+    return !(p.ablate & 8);
+#else
+    (void)p;
+    return true;
+#endif
+}
+
 template <typename DT>
 __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
 {
@@ -550,7 +562,9 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     // rows past M re-read the last row (their outputs are never stored)
     const unsigned rowb = (unsigned)(p.Cin * ES);
     auto stage_a = [&](int i, int c, int abuf) {
+#ifdef TDRN_DEV_ABLATE
         if (p.ablate & 1) return;
+#endif
         const int ln = opaque_lane();
         const int lrow = ln >> 3, pc = ln & 7;
         const int mt = mt_of(seq_item(i));
@@ -563,7 +577,9 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
         }
     };
     auto stage_w = [&](int i, int c, int wbuf) {
+#ifdef TDRN_DEV_ABLATE
         if (p.ablate & 2) return;
+#endif
         const int ln = opaque_lane();
         const int lrow = ln >> 3, pc = ln & 7;
         const int wcn = seq_wcn(i);                     // my group's rows: 32 wcn of them, behind the (sub-)item's first cout
@@ -594,7 +610,9 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
     };
     auto mma_phase = [&](auto wcn_tag, int abuf, int wbuf, int h0 = 0, int h1 = 2) {
         constexpr int WCN = decltype(wcn_tag)::value;   // accumulator tiles per wave along the couts: 4 (whole item), 2, 1 (tail sub-items)
+#ifdef TDRN_DEV_ABLATE
         if (p.ablate & 4) return;
+#endif
         const int ln = opaque_lane();
         const int r32 = ln & 31, hh = ln >> 5;
         const unsigned wa = (unsigned)(OFF_W + wbuf * WBYTES + grp * (WBYTES / 2) + r32 * 128 + ((hh ^ ((r32 >> 1) & 7)) << 4));
@@ -685,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void pw1x1_kernel(const Pw1x1Params p)
                 for (int k = 0; k < 4; ++k) {
                     const int row = orow + 8 * k;
                     const long long gp = pix0 + pt * 32 + row;
-                    if (gp < p.M && my_c < p.Cout && och_ok && !(p.ablate & 8))
+                    if (gp < p.M && my_c < p.Cout && och_ok && pw_store_on(p))
                         *(u32x4 *)(p.out + ((size_t)gp * p.Cs + my_c) * ES) = *(const u32x4 *)(stg + row * SST + och * 16);
                 }
                 __builtin_amdgcn_wave_barrier();
