@@ -247,7 +247,7 @@ typedef struct {
                                        differ in their last bits)                                                                        */
 #define TDRN_PLAN_TS_ONE_RANGE  65536 /* transform-then-sample heads: the whole batch as ONE range (Y of the whole batch in its buffer) instead of ranges
                                        whose Y fits the memory-side cache (192 MiB); same bits -- for tools and tests that read Y back       */
-#define TDRN_PLAN_NO_PATCH_TAIL 131072 /* conv3x3_patch.hip runs whole 128-cout items only: no 64-cout half items in an XCD's last, at most half-filled
+#define TDRN_PLAN_NO_PATCH_TAIL 131072 /* conv3x3_patch.hip and dwpw.hip pw1x1_kernel run whole items only: no 64- / 128-cout sub-items in an XCD's last, sparsely filled
                                         * round (the tail split of round 6: same MFMA rows, same K order -- bit-identical; for A/B runs and the test) */
 #define TDRN_PLAN_FAULT_HANDOFF 256 /* fault injection (tests only): producers of the chained split never raise their flag, so the
                                        consumers' bounded polls run out -> the forward is reported failed, it does not hang          */

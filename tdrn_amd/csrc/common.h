@@ -14,7 +14,7 @@ namespace tdrn {
 // in the product library a stray environment variable cannot poison a result.
 // What the product library DOES read from the environment (each once, cached per process; all listed in INTEGRATION.md "Environment
 // knobs"): kernel-CHOICE and schedule switches -- TDRN_CONV_PATCH / _PP / _PP_SK / _PP_POOL / _PP_NMAJOR / _WS / _VARIANT, TDRN_PW1X1,
-// TDRN_PW_NMAJOR, TDRN_DWPW, TDRN_DW_SLIDE / _STRIP, TDRN_FIRST_MFMA, TDRN_FUSE_FIRST, TDRN_IGEMM_BATCH_MINOR, TDRN_SPLITK(_REF),
+// TDRN_PW_NMAJOR, TDRN_PW_STAGGER, TDRN_DWPW, TDRN_DW_SLIDE / _STRIP, TDRN_FIRST_MFMA, TDRN_FUSE_FIRST, TDRN_IGEMM_BATCH_MINOR, TDRN_SPLITK(_REF),
 // TDRN_PATCH_SMALL_BN, TDRN_DEFORM_TS / _SPLIT / _XCD, TDRN_SAMPLE_XCD, TDRN_YGEMM_V2 / _CT / _MULTI, TDRN_Y_TAP_MAJOR, TDRN_TS_RANGE_MB, TDRN_PATCH_TAIL,
 // TDRN_STREAMS, TDRN_L2_EARLY, TDRN_LATE_SIDE, TDRN_MAIN_GRID, TDRN_SIDE_GRID, TDRN_CHAIN, TDRN_PLAN_DUMP.  Every one of them selects
 // among implementations that the GPU tests hold to the same results (bit-identical where tests/test_gpu_pin16.py says so, fp32
